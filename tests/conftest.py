@@ -1,0 +1,48 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
+
+
+@pytest.fixture(scope="session")
+def g1():
+    return load_golden("g1_reference_fixture.npz")
+
+
+@pytest.fixture(scope="session")
+def g2():
+    return load_golden("g2_mini_street.npz")
+
+
+@pytest.fixture(scope="session")
+def g3():
+    return load_golden("g3_voxels.npz")
+
+
+@pytest.fixture(scope="session")
+def g5():
+    return load_golden("g5_se3.npz")
+
+
+@pytest.fixture(scope="session")
+def g6():
+    return load_golden("g6_normals.npz")
+
+
+def rel_H(H, Href):
+    """Parity metric of SURVEY.md section 8a Q5: max|dH| / max|H_ref|."""
+    return float(np.max(np.abs(np.asarray(H) - np.asarray(Href))) / np.max(np.abs(Href)))

@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference.
+
+Run in the authoring container only (the reference lives at /root/reference and never
+travels to the GPU box):
+
+    python tests/golden/make_golden.py
+
+``pykdtree`` (the reference's default KD-tree backend, ``kdtree.py:6,18-21``) is not
+installable here, so a ``sys.modules`` shim backed by ``scipy.spatial.cKDTree`` is
+registered before the import.  Exact 1-NN has a unique answer up
+to exact ties, so any exact backend is a valid stand-in for that third-party component.
+
+Outputs are DATA only (inputs + the reference's outputs), stored as small .npz files.
+"""
+
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = "/root/reference"
+
+
+def install_pykdtree_shim():
+    from scipy.spatial import cKDTree
+
+    class KDTree:                                   # pykdtree.kdtree.KDTree stand-in
+        def __init__(self, data, leafsize=16):
+            self._dtype = np.asarray(data).dtype
+            self._tree = cKDTree(np.asarray(data, dtype=np.float64), leafsize=leafsize)
+
+        def query(self, pts, k=1, **kw):
+            d, i = self._tree.query(np.asarray(pts, dtype=np.float64), k=k)
+            return d.astype(self._dtype if self._dtype.kind == "f" else np.float64), i
+
+    pkg = types.ModuleType("pykdtree")
+    mod = types.ModuleType("pykdtree.kdtree")
+    mod.KDTree = KDTree
+    pkg.kdtree = mod
+    sys.modules["pykdtree"] = pkg
+    sys.modules["pykdtree.kdtree"] = mod
+
+
+install_pykdtree_shim()
+sys.path.insert(0, REFERENCE)
+sys.path.insert(0, REPO)
+
+import point_cloud_registration as ref                       # noqa: E402  (the reference)
+from point_cloud_registration.voxel import get_keys          # noqa: E402
+from point_cloud_registration_amd.synthetic import street    # noqa: E402  (own generator)
+
+
+def non_identity_T():
+    T = np.eye(4)
+    T[:3, :3] = ref.expSO3(np.array([0.03, -0.05, 0.04]))
+    T[:3, 3] = [0.07, -0.04, 0.09]
+    return T
+
+
+def triple(x):
+    H, g, e2 = x
+    return np.asarray(H, dtype=np.float64), np.asarray(g, dtype=np.float64), np.float64(e2)
+
+
+def run_four(target, source, cur_T, max_dist, voxel_size, k, out, tag):
+    """calc_H_g_e2 of the four reference classes at cur_T -> out[...]."""
+    icp = ref.ICP(max_dist=max_dist)
+    icp.set_target(target)
+    out[f"{tag}_icp_H"], out[f"{tag}_icp_g"], out[f"{tag}_icp_e2"] = triple(icp.calc_H_g_e2(cur_T, source))
+
+    picp = ref.PlaneICP(max_dist=max_dist, k=k)
+    picp.set_target(target)
+    out[f"{tag}_plane_H"], out[f"{tag}_plane_g"], out[f"{tag}_plane_e2"] = triple(picp.calc_H_g_e2(cur_T, source))
+
+    vp = ref.VPlaneICP(voxel_size=voxel_size, max_dist=max_dist)
+    vp.set_target(target)
+    out[f"{tag}_vplane_H"], out[f"{tag}_vplane_g"], out[f"{tag}_vplane_e2"] = triple(vp.calc_H_g_e2(cur_T, source))
+
+    ndt = ref.NDT(voxel_size=voxel_size, max_dist=max_dist)
+    ndt.set_target(target)
+    out[f"{tag}_ndt_H"], out[f"{tag}_ndt_g"], out[f"{tag}_ndt_e2"] = triple(ndt.calc_H_g_e2(cur_T, source))
+    return icp, picp, vp, ndt
+
+
+def g1():
+    """The reference tests' own fixture (tests/test_icp.py:7-17 etc.)."""
+    np.random.seed(42)
+    target = np.random.rand(100, 3)
+    R = ref.expSO3(np.array([0.1, 0.2, 0.3]))
+    t = np.array([0.5, -0.3, 0.2])
+    source = ((R @ target.T).T + t).astype(np.float32)
+    out = {"target": target, "source": source, "max_dist": 2.0, "voxel_size": 1.0, "k": 15}
+    icp, picp, vp, ndt = run_four(target, source, np.eye(4), 2.0, 1.0, 15, out, "I")
+    T = non_identity_T()
+    out["T"] = T
+    run_four(target, source, T, 2.0, 1.0, 15, out, "T")
+    out["plane_normals"] = np.asarray(picp.normal)
+    out["vox_mean"], out["vox_norm"], out["vox_cov"] = vp.voxels.mean, vp.voxels.norm, vp.voxels.cov
+    out["vox_icov"] = ndt.voxels.icov
+    # loop ("no_parallel_ver") oracles at identity, where they are valid (nothing masked)
+    out["I_icp_loop_H"], out["I_icp_loop_g"], out["I_icp_loop_e2"] = triple(
+        icp.calc_H_g_e2_no_parallel_ver(np.eye(4), source))
+    np.savez_compressed(os.path.join(HERE, "g1_reference_fixture.npz"), **out)
+    print("G1 ICP diag(H):", np.diag(out["I_icp_H"]), "e2", out["I_icp_e2"])
+    print("G1 PlaneICP e2", out["I_plane_e2"], " VPlaneICP e2", out["I_vplane_e2"], " NDT e2", out["I_ndt_e2"])
+
+
+def mini_street(n, seed, scale=0.1):
+    return (street(n, seed=seed).astype(np.float64) * scale).astype(np.float32)
+
+
+def g2():
+    """Multi-voxel, masked, non-identity case + full align() trajectories."""
+    target = mini_street(5000, seed=7)
+    rng = np.random.default_rng(11)
+    T_true = np.eye(4)
+    T_true[:3, :3] = ref.expSO3(np.array([0.02, -0.03, 0.025]))
+    T_true[:3, 3] = [0.06, 0.03, -0.05]
+    pick = rng.choice(target.shape[0], 1800, replace=False)
+    Rinv = T_true[:3, :3].T
+    scan = (Rinv @ target[pick].astype(np.float64).T).T - Rinv @ T_true[:3, 3]
+    scan += rng.normal(0, 0.003, scan.shape)
+    # 200 outliers far enough from the cloud that the gate removes a good part of them
+    outl = rng.uniform([-7, -4, 2.2], [7, 4, 3.5], (200, 3))
+    scan = np.vstack([scan, outl]).astype(np.float32)
+    max_dist, voxel_size, k = 0.8, 1.0, 10
+    cur_T = non_identity_T()
+    out = {"target": target, "source": scan, "max_dist": max_dist, "voxel_size": voxel_size,
+           "k": k, "T": cur_T, "T_true": T_true}
+    icp, picp, vp, ndt = run_four(target, scan, cur_T, max_dist, voxel_size, k, out, "T")
+    # correspondence-level data at cur_T
+    src_trans = ref.transform_points(cur_T.astype(np.float32), scan)
+    d, i = icp.kdtree.query(src_trans)
+    out["nn_dist"], out["nn_idx"] = d, i
+    q = vp.voxels.query(src_trans, ["mean"])
+    dv, iv = vp.voxels.kdtree.query(src_trans)
+    out["vox_dist"], out["vox_idx"] = dv, iv
+    out["plane_normals"] = np.asarray(picp.normal)
+    out["vox_mean"], out["vox_norm"], out["vox_cov"] = vp.voxels.mean, vp.voxels.norm, vp.voxels.cov
+    out["vox_icov"] = ndt.voxels.icov
+    print("G2 masked fraction (points):", 1 - np.mean(d < max_dist), " (voxels):", 1 - np.mean(dv < max_dist),
+          " n_vox", vp.voxels.mean.shape[0])
+
+    # full align trajectories
+    for name, obj in (("icp", icp), ("plane", picp), ("vplane", vp), ("ndt", ndt)):
+        cur = np.eye(4)
+        traj_T, traj_H, traj_g, traj_e2 = [], [], [], []
+        src32 = scan.astype(np.float32)
+        for _ in range(obj.max_iter):
+            H, g, e2 = triple(obj.calc_H_g_e2(cur, src32))
+            traj_T.append(cur.copy()); traj_H.append(H); traj_g.append(g); traj_e2.append(e2)
+            dx = -np.linalg.solve(H, g)
+            if np.linalg.norm(dx) < obj.tol:
+                break
+            cur = ref.plus(cur, dx)
+        final = obj.align(scan, np.eye(4))
+        assert np.allclose(final, cur)
+        out[f"align_{name}_T"] = np.array(traj_T)
+        out[f"align_{name}_H"] = np.array(traj_H)
+        out[f"align_{name}_g"] = np.array(traj_g)
+        out[f"align_{name}_e2"] = np.array(traj_e2)
+        out[f"align_{name}_final"] = final
+        print(f"G2 align {name}: {len(traj_T)} iters, |t err| = "
+              f"{np.linalg.norm(final[:3, 3] - T_true[:3, 3]):.2e}")
+    np.savez_compressed(os.path.join(HERE, "g2_mini_street.npz"), **out)
+
+
+def g3():
+    """Voxel build goldens at two voxel sizes, f32 input (the PCD case) and f64 input."""
+    out = {}
+    base = mini_street(6000, seed=3)
+    for dtype_name, pts in (("f32", base), ("f64", base.astype(np.float64) + 1e-9)):
+        out[f"points_{dtype_name}"] = pts
+        for vs in (0.5, 1.0):
+            tag = f"{dtype_name}_vs{vs}"
+            keys = get_keys(pts, vs)
+            uniq, inv = np.unique(keys, return_inverse=True)
+            counts = np.bincount(inv)
+            grid = ref.VoxelGrid(vs)
+            grid.set_points(pts)
+            grid.calc_icov()
+            w = np.linalg.eigvalsh(grid.cov)
+            out[f"{tag}_keys"] = keys
+            out[f"{tag}_uniq"] = uniq
+            out[f"{tag}_counts"] = counts
+            out[f"{tag}_mean"] = grid.mean
+            out[f"{tag}_cov"] = grid.cov
+            out[f"{tag}_icov"] = grid.icov
+            out[f"{tag}_norm"] = grid.norm
+            out[f"{tag}_evals"] = w
+            print(f"G3 {tag}: {len(uniq)} voxels, {grid.mean.shape[0]} kept")
+    np.savez_compressed(os.path.join(HERE, "g3_voxels.npz"), **out)
+
+
+def g5():
+    """expSO3 / plus either side of the theta^2 <= 1e-5 first-order branch (quirk Q3)."""
+    omegas = np.array([[0.0, 0.0, 0.0],
+                       [0.001, -0.002, 0.0015],
+                       [np.sqrt(1e-5) * 0.999, 0, 0],
+                       [np.sqrt(1e-5) * 1.001, 0, 0],
+                       [0.0018, 0.0018, 0.0019],
+                       [0.1, 0.2, 0.3],
+                       [-1.2, 0.4, 2.0]])
+    Rs = np.array([ref.expSO3(w) for w in omegas])
+    T0 = non_identity_T()
+    dxs = np.hstack([np.linspace(-0.2, 0.3, len(omegas))[:, None] * np.array([[1.0, -0.5, 0.25]]), omegas])
+    Ts = np.array([ref.plus(T0, dx) for dx in dxs])
+    np.savez_compressed(os.path.join(HERE, "g5_se3.npz"), omegas=omegas, Rs=Rs, T0=T0, dxs=dxs, Ts=Ts)
+
+
+def g6():
+    """k-NN PCA normals (estimate_norm_with_tree) on a small cloud, k in {5, 15}."""
+    pts = mini_street(3000, seed=5)
+    out = {"points": pts}
+    for k in (5, 15):
+        n = ref.estimate_normals(pts, k=k)
+        out[f"normals_k{k}"] = n
+    # the planar reference cloud, exaggerated scale, to expose the f32 single-pass covariance
+    np.savez_compressed(os.path.join(HERE, "g6_normals.npz"), **out)
+
+
+if __name__ == "__main__":
+    g1(); g2(); g3(); g5(); g6()
+    print("done")
