@@ -1,0 +1,175 @@
+/*
+ * pcr.h -- C ABI of the MI355X-native point-cloud registration core (libpcr_hip.so).
+ *
+ * The reference (scomup/point-cloud-registration) is pure Python/NumPy and has no FFI of
+ * its own; its seams are Python duck types.  This header is the
+ * drop-in boundary a maintainer would bind with ctypes from inside the reference's classes
+ * (INTEGRATION.md shows the stub).  Every entry point names the reference interface it
+ * replaces (paths relative to /root/reference/point_cloud_registration/).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, opaque handles; no C++/torch types.
+ *   - every function returns a pcr_status (0 = PCR_OK); pcr_last_error() gives the message
+ *     of the last failure on the calling thread.
+ *   - host buffers are caller-owned, read (or written) during the call and never retained;
+ *     *_device variants take device pointers valid on the context's GPU.
+ *   - one context = one GPU = one HIP stream; handles are not thread-safe; calls that
+ *     return data to the host are synchronous on return.
+ *   - one process drives one GPU; multi-GPU = one process per GPU joined with
+ *     pcr_comm_init (RCCL over xGMI), the scan sharded across ranks.
+ *   - point clouds are float32 (N,3) row-major unless stated.  4x4 transforms are float64
+ *     row-major.  The normal equations come back as out[29]:
+ *       out[0..20]  upper triangle of H (6x6) row-major: 00 01 02 03 04 05 11 12 .. 55
+ *       out[21..26] g,  out[27] e2,  out[28] number of correspondences that passed the gate
+ */
+#ifndef PCR_H
+#define PCR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCR_API __attribute__((visibility("default")))
+
+typedef int pcr_status;
+enum {
+    PCR_OK = 0,
+    PCR_ERR_INVALID = -1,     /* bad argument */
+    PCR_ERR_HIP = -2,         /* HIP runtime failure (message has the HIP error string) */
+    PCR_ERR_NO_TARGET = -3,   /* target lacks what the requested kind needs (normals / icov) */
+    PCR_ERR_COMM = -4,        /* RCCL failure or communicator misuse */
+    PCR_ERR_SINGULAR = -5,    /* pcr_align: H singular (zero correspondences); quirk Q7 */
+    PCR_ERR_NOMEM = -6
+};
+
+/* registration kinds: which reference class's calc_H_g_e2 is evaluated */
+enum {
+    PCR_ICP = 0,      /* icp.py:24-57 */
+    PCR_PLANE = 1,    /* plane_icp.py:30-69 */
+    PCR_VPLANE = 2,   /* voxelized_plane_icp.py:23-64 */
+    PCR_NDT = 3       /* ndt.py:24-57 */
+};
+
+/* compat flags */
+enum {
+    PCR_FLAG_ICP_RR_QUIRK = 1u,   /* reproduce icp.py:53-54: g[3:] = sum p x (R r) (quirk Q1); default */
+    PCR_FLAG_NO_SCAN_SORT = 2u    /* pcr_scan_create: keep the caller's point order on the device */
+};
+
+typedef struct pcr_context pcr_context;
+typedef struct pcr_target pcr_target;
+typedef struct pcr_scan pcr_scan;
+
+/* ---- library / context ------------------------------------------------------------ */
+PCR_API const char *pcr_last_error(void);
+PCR_API const char *pcr_version(void);
+PCR_API pcr_status pcr_device_count(int *count);
+PCR_API pcr_status pcr_context_create(int device, pcr_context **out);
+PCR_API pcr_status pcr_context_destroy(pcr_context *ctx);
+/* the context's HIP stream (hipStream_t as void*), for callers that order their own work */
+PCR_API pcr_status pcr_context_stream(pcr_context *ctx, void **stream);
+PCR_API pcr_status pcr_context_synchronize(pcr_context *ctx);
+
+/* ---- multi-GPU: one process per GPU, RCCL all-reduce of the 29 doubles per iteration ----
+ * No reference counterpart (the reference is single-process).  Rank 0 obtains an id with
+ * pcr_comm_unique_id and distributes the 128 bytes out of band (bench.py uses
+ * torch.distributed); every rank then calls pcr_comm_init.  After that pcr_linearize /
+ * pcr_align return the SUM over all ranks' scan shards.                                  */
+PCR_API pcr_status pcr_comm_unique_id(void *id128);
+PCR_API pcr_status pcr_comm_init(pcr_context *ctx, const void *id128, int nranks, int rank);
+PCR_API pcr_status pcr_comm_destroy(pcr_context *ctx);
+
+/* ---- targets ------------------------------------------------------------------------
+ * pcr_target_points_create replaces ICP.set_target (icp.py:17-22) and the KD-tree half of
+ * PlaneICP.set_target (plane_icp.py:19-22): float32 copy of the cloud + an exact-NN index
+ * (a dense cell grid in HBM instead of pykdtree's KD-tree, kdtree.py:18-21).
+ * normals (N,3) float32 may be NULL; cell_hint = 0 picks the cell size automatically.     */
+PCR_API pcr_status pcr_target_points_create(pcr_context *ctx, const float *xyz, int64_t n,
+                                            const float *normals_or_null, float cell_hint,
+                                            pcr_target **out);
+PCR_API pcr_status pcr_target_points_create_device(pcr_context *ctx, const float *d_xyz, int64_t n,
+                                                   const float *d_normals_or_null, float cell_hint,
+                                                   pcr_target **out);
+/* caller-supplied normals, PlaneICP.set_target(target, kdree, norm) (plane_icp.py:25-27)  */
+PCR_API pcr_status pcr_target_set_normals(pcr_target *t, const float *normals);
+/* k-NN PCA normals, estimate_norm_with_tree (estimate_normals.py:27-87).  compat != 0 keeps
+ * the reference's float32 single-pass covariance; normals_out (N,3) may be NULL.           */
+PCR_API pcr_status pcr_target_estimate_normals(pcr_target *t, int k, int compat, float *normals_out);
+PCR_API pcr_status pcr_target_get_normals(pcr_target *t, float *normals_out);
+
+/* Voxel targets, VPlaneICP.set_target / NDT.set_target (voxelized_plane_icp.py:18-21,
+ * ndt.py:18-22) = VoxelGrid.set_points + calc_icov (voxel.py:104-165, 69-102) built on the
+ * GPU: hash keys (voxel.py:12-21), group, mean, two-pass covariance, min_points filter,
+ * smallest-eigenvector normal, closed-form inverse covariance, and an exact
+ * nearest-CENTROID index (voxel.py:165,171-179).  xyz_is_f64 selects the dtype the keys
+ * are computed in (float32 clouds divide in float32, as NumPy does).                      */
+PCR_API pcr_status pcr_target_voxels_create(pcr_context *ctx, const void *xyz, int xyz_is_f64, int64_t n,
+                                            double voxel_size, int min_points, pcr_target **out);
+/* the same from precomputed statistics (mean, norm: (n_v,3) float64; icov: (n_v,3,3) float64,
+ * norm / icov may be NULL): lets tests inject the oracle's voxels for kernel-only parity.   */
+PCR_API pcr_status pcr_target_voxels_create_from_stats(pcr_context *ctx, const double *mean,
+                                                       const double *norm_or_null, const double *icov_or_null,
+                                                       int64_t n_v, double voxel_size, pcr_target **out);
+/* read the voxel statistics back (any pointer may be NULL); *n_v is always written          */
+PCR_API pcr_status pcr_target_voxels_get(pcr_target *t, int64_t *n_v, double *mean, double *cov,
+                                         double *norm, double *icov, int64_t *counts, int64_t *keys);
+PCR_API pcr_status pcr_target_size(pcr_target *t, int64_t *n);
+PCR_API pcr_status pcr_target_destroy(pcr_target *t);
+
+/* ---- scan ---------------------------------------------------------------------------
+ * Registration.align casts the scan to float32 once (registration.py:83) and reuses it for
+ * every iteration: uploaded once, Morton-sorted on the device for gather coherence (the
+ * sums do not depend on point order beyond rounding).                                      */
+PCR_API pcr_status pcr_scan_create(pcr_context *ctx, const float *xyz, int64_t n, unsigned flags, pcr_scan **out);
+PCR_API pcr_status pcr_scan_create_device(pcr_context *ctx, const float *d_xyz, int64_t n, unsigned flags,
+                                          pcr_scan **out);
+PCR_API pcr_status pcr_scan_size(pcr_scan *s, int64_t *n);
+PCR_API pcr_status pcr_scan_destroy(pcr_scan *s);
+
+/* ---- the hot path ---------------------------------------------------------------------
+ * One calc_H_g_e2: transform (math_tools.py:111-113) -> exact 1-NN (kdtree.py:18-21 /
+ * voxel.py:171-179) -> gate dist < max_dist -> residual + Jacobian -> 6x6 normal equations
+ * (icp.py:24-57, plane_icp.py:30-69, voxelized_plane_icp.py:23-64, ndt.py:24-57), summed
+ * over all ranks when a communicator is attached.  The search is bounded by max_dist, which
+ * is exact for these sums (anything farther is gated out anyway).                          */
+PCR_API pcr_status pcr_linearize(pcr_target *t, pcr_scan *s, int kind, const double T[16],
+                                 double max_dist, unsigned flags, double out[29]);
+
+/* Registration.align (registration.py:71-113) run entirely behind the boundary: up to
+ * max_iter x { pcr_linearize, dx = -solve(H, g), stop if |dx| < tol (before the update,
+ * quirk Q4), T <- plus(T, dx) (math_tools.py:101-108, first-order expSO3 branch, quirk Q3) }.
+ * trace_or_null receives up to max_iter rows of 16 (T before the step) + 29 doubles.
+ * Returns PCR_ERR_SINGULAR where numpy.linalg.solve would raise LinAlgError (quirk Q7).     */
+PCR_API pcr_status pcr_align(pcr_target *t, pcr_scan *s, int kind, const double T_init[16],
+                             int max_iter, double tol, double max_dist, unsigned flags,
+                             double T_out[16], int *iterations, double *trace_or_null);
+
+/* ---- fine seam: KDTree(data).query(points, k) (kdtree.py:18-65) ------------------------
+ * dist is Euclidean (not squared).  For point targets dist is float32 and idx indexes the
+ * array given to pcr_target_points_create; for voxel targets use the f64 variant (idx =
+ * kept-voxel index).  r_max <= 0 or inf = unbounded (as the reference); with a bound,
+ * queries with no neighbour inside r_max get idx = -1, dist = inf.                         */
+PCR_API pcr_status pcr_nn_query(pcr_target *t, const float *q, int64_t m, float r_max, float *dist, int64_t *idx);
+PCR_API pcr_status pcr_nn_query_f64(pcr_target *t, const float *q, int64_t m, double r_max, double *dist, int64_t *idx);
+PCR_API pcr_status pcr_knn_query(pcr_target *t, const float *q, int64_t m, int k, float *dist, int64_t *idx);
+
+/* ---- instrumentation ------------------------------------------------------------------
+ * With profiling on, every launch of a hot-path kernel is bracketed by HIP events on the
+ * context's stream; pcr_profile_read drains them (synchronises) and reports per-kernel
+ * launch count and total milliseconds since the last reset.                                */
+enum { PCR_K_LINEARIZE = 0, PCR_K_FINALIZE = 1, PCR_K_NN = 2, PCR_K_REDUCE = 3, PCR_K_ALLREDUCE = 4, PCR_K_COUNT = 5 };
+PCR_API pcr_status pcr_profile_enable(pcr_context *ctx, int on);
+PCR_API pcr_status pcr_profile_reset(pcr_context *ctx);
+PCR_API pcr_status pcr_profile_read(pcr_context *ctx, int64_t launches[PCR_K_COUNT], double total_ms[PCR_K_COUNT]);
+/* grid geometry of a target's NN index: cell size, dims, occupied cells, points (or voxels) */
+PCR_API pcr_status pcr_target_index_info(pcr_target *t, double *cell, int64_t dims[3], int64_t *occupied, int64_t *n);
+/* select the hot-path variant: 0 = fused transform+NN+reduce kernel (default), 1 = NN kernel
+ * writing correspondences to HBM followed by a reduce kernel                               */
+PCR_API pcr_status pcr_set_variant(pcr_context *ctx, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCR_H */

@@ -1,0 +1,352 @@
+"""ctypes binding of libpcr_hip.so (include/pcr.h) -- the only way the Python host reaches the GPU.
+
+There is NO CPU fallback: if the HIP library is missing or no MI355X is visible, the calls
+raise.  (The CPU restatement under oracle/ is test infrastructure and is never imported here.)
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpcr_hip.so")
+
+PCR_OK = 0
+PCR_ERR_INVALID, PCR_ERR_HIP, PCR_ERR_NO_TARGET, PCR_ERR_COMM, PCR_ERR_SINGULAR, PCR_ERR_NOMEM = -1, -2, -3, -4, -5, -6
+ICP, PLANE, VPLANE, NDT = 0, 1, 2, 3
+FLAG_ICP_RR_QUIRK = 1
+FLAG_NO_SCAN_SORT = 2
+K_LINEARIZE, K_FINALIZE, K_NN, K_REDUCE, K_ALLREDUCE, K_COUNT = 0, 1, 2, 3, 4, 5
+KERNEL_NAMES = ("linearize", "finalize", "nn", "reduce", "allreduce")
+
+_lib = None
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); also the list of symbols the library must export
+PROTOTYPES = {
+    "pcr_last_error": (C.c_char_p, []),
+    "pcr_version": (C.c_char_p, []),
+    "pcr_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "pcr_context_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "pcr_context_destroy": (C.c_int, [_vp]),
+    "pcr_context_stream": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "pcr_context_synchronize": (C.c_int, [_vp]),
+    "pcr_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "pcr_comm_init": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int]),
+    "pcr_comm_destroy": (C.c_int, [_vp]),
+    "pcr_target_points_create": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_float, C.POINTER(_vp)]),
+    "pcr_target_points_create_device": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_float, C.POINTER(_vp)]),
+    "pcr_target_set_normals": (C.c_int, [_vp, _f32p]),
+    "pcr_target_estimate_normals": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "pcr_target_get_normals": (C.c_int, [_vp, _f32p]),
+    "pcr_target_voxels_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_double, C.c_int, C.POINTER(_vp)]),
+    "pcr_target_voxels_create_from_stats": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_double, C.POINTER(_vp)]),
+    "pcr_target_voxels_get": (C.c_int, [_vp, C.POINTER(C.c_int64), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pcr_target_size": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    "pcr_target_destroy": (C.c_int, [_vp]),
+    "pcr_scan_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_uint, C.POINTER(_vp)]),
+    "pcr_scan_create_device": (C.c_int, [_vp, _vp, C.c_int64, C.c_uint, C.POINTER(_vp)]),
+    "pcr_scan_size": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    "pcr_scan_destroy": (C.c_int, [_vp]),
+    "pcr_linearize": (C.c_int, [_vp, _vp, C.c_int, _f64p, C.c_double, C.c_uint, _f64p]),
+    "pcr_align": (C.c_int, [_vp, _vp, C.c_int, _f64p, C.c_int, C.c_double, C.c_double, C.c_uint, _f64p,
+                            C.POINTER(C.c_int), _vp]),
+    "pcr_nn_query": (C.c_int, [_vp, _f32p, C.c_int64, C.c_float, _f32p, _i64p]),
+    "pcr_nn_query_f64": (C.c_int, [_vp, _f32p, C.c_int64, C.c_double, _f64p, _i64p]),
+    "pcr_knn_query": (C.c_int, [_vp, _f32p, C.c_int64, C.c_int, _f32p, _i64p]),
+    "pcr_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "pcr_profile_reset": (C.c_int, [_vp]),
+    "pcr_profile_read": (C.c_int, [_vp, _i64p, _f64p]),
+    "pcr_target_index_info": (C.c_int, [_vp, C.POINTER(C.c_double), _i64p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "pcr_set_variant": (C.c_int, [_vp, C.c_int]),
+}
+
+
+class PcrError(RuntimeError):
+    """HIP / RCCL / argument failure reported by libpcr_hip.so."""
+
+
+def lib():
+    """Load libpcr_hip.so (built in-tree by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PcrError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the registration hot path.")
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(L, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(status):
+    if status == PCR_OK:
+        return
+    msg = lib().pcr_last_error().decode("utf-8", "replace")
+    if status == PCR_ERR_SINGULAR:
+        raise np.linalg.LinAlgError("Singular matrix")          # what numpy.linalg.solve raises (quirk Q7)
+    if status == PCR_ERR_INVALID:
+        raise ValueError(msg)
+    if status == PCR_ERR_NO_TARGET:
+        raise ValueError(msg)
+    raise PcrError(f"libpcr_hip status {status}: {msg}")
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().pcr_device_count(C.byref(n)))
+    return n.value
+
+
+class Context:
+    """One GPU + one HIP stream (pcr_context)."""
+
+    def __init__(self, device=0):
+        self.device = int(device)
+        h = _vp()
+        check(lib().pcr_context_create(self.device, C.byref(h)))
+        self.handle = h
+        self.nranks, self.rank = 1, 0
+
+    def synchronize(self):
+        check(lib().pcr_context_synchronize(self.handle))
+
+    def stream(self):
+        s = _vp()
+        check(lib().pcr_context_stream(self.handle, C.byref(s)))
+        return s.value
+
+    def set_variant(self, v):
+        check(lib().pcr_set_variant(self.handle, int(v)))
+
+    # -- RCCL
+    def comm_init(self, uid, nranks, rank):
+        check(lib().pcr_comm_init(self.handle, uid, int(nranks), int(rank)))
+        self.nranks, self.rank = int(nranks), int(rank)
+
+    def comm_destroy(self):
+        check(lib().pcr_comm_destroy(self.handle))
+        self.nranks, self.rank = 1, 0
+
+    # -- profiling
+    def profile_enable(self, on=True):
+        check(lib().pcr_profile_enable(self.handle, int(bool(on))))
+
+    def profile_reset(self):
+        check(lib().pcr_profile_reset(self.handle))
+
+    def profile_read(self):
+        n = np.zeros(K_COUNT, np.int64)
+        ms = np.zeros(K_COUNT, np.float64)
+        check(lib().pcr_profile_read(self.handle, n, ms))
+        return {KERNEL_NAMES[i]: (int(n[i]), float(ms[i])) for i in range(K_COUNT)}
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().pcr_context_destroy(self.handle)
+            self.handle = None
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(128)
+    check(lib().pcr_comm_unique_id(buf))
+    return buf.raw
+
+
+_contexts = {}
+
+
+def get_context(device=None):
+    """Process-wide context per device; default device = LOCAL_RANK (one process per GPU)."""
+    if device is None:
+        device = int(os.environ.get("PCR_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        n = device_count()
+        if n > 0:
+            device %= n
+    if device not in _contexts:
+        _contexts[device] = Context(device)
+    return _contexts[device]
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+class Target:
+    """pcr_target handle (point target or voxel target)."""
+
+    def __init__(self, ctx, handle, is_voxel):
+        self.ctx, self.handle, self.is_voxel = ctx, handle, is_voxel
+
+    @classmethod
+    def points(cls, ctx, xyz, normals=None, cell_hint=0.0):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        if normals is not None:
+            normals = np.ascontiguousarray(normals, dtype=np.float32)
+            if normals.shape != xyz.shape:
+                raise ValueError("normals must have the shape of the target")
+        h = _vp()
+        check(lib().pcr_target_points_create(ctx.handle, _ptr(xyz), xyz.shape[0], _ptr(normals),
+                                             float(cell_hint), C.byref(h)))
+        return cls(ctx, h, False)
+
+    @classmethod
+    def points_device(cls, ctx, d_xyz, n, d_normals=None, cell_hint=0.0):
+        h = _vp()
+        check(lib().pcr_target_points_create_device(ctx.handle, _vp(d_xyz), int(n),
+                                                    _vp(d_normals) if d_normals else None,
+                                                    float(cell_hint), C.byref(h)))
+        return cls(ctx, h, False)
+
+    @classmethod
+    def voxels(cls, ctx, xyz, voxel_size, min_points=10):
+        a = np.asarray(xyz)
+        is64 = a.dtype == np.float64
+        a = np.ascontiguousarray(a, dtype=np.float64 if is64 else np.float32)
+        h = _vp()
+        check(lib().pcr_target_voxels_create(ctx.handle, _ptr(a), int(is64), a.shape[0], float(voxel_size),
+                                             int(min_points), C.byref(h)))
+        return cls(ctx, h, True)
+
+    @classmethod
+    def voxels_from_stats(cls, ctx, mean, norm, icov, voxel_size):
+        mean = np.ascontiguousarray(mean, dtype=np.float64)
+        norm = None if norm is None else np.ascontiguousarray(norm, dtype=np.float64)
+        icov = None if icov is None else np.ascontiguousarray(icov, dtype=np.float64)
+        h = _vp()
+        check(lib().pcr_target_voxels_create_from_stats(ctx.handle, _ptr(mean), _ptr(norm), _ptr(icov),
+                                                        mean.shape[0], float(voxel_size), C.byref(h)))
+        return cls(ctx, h, True)
+
+    def size(self):
+        n = C.c_int64(0)
+        check(lib().pcr_target_size(self.handle, C.byref(n)))
+        return n.value
+
+    def set_normals(self, normals):
+        check(lib().pcr_target_set_normals(self.handle, np.ascontiguousarray(normals, dtype=np.float32)))
+
+    def estimate_normals(self, k=15, compat=True, want=True):
+        out = np.empty((self.size(), 3), np.float32) if want else None
+        check(lib().pcr_target_estimate_normals(self.handle, int(k), int(bool(compat)), _ptr(out)))
+        return out
+
+    def get_normals(self):
+        out = np.empty((self.size(), 3), np.float32)
+        check(lib().pcr_target_get_normals(self.handle, out))
+        return out
+
+    def voxel_stats(self, names=("mean", "cov", "norm", "icov", "counts", "keys")):
+        n = self.size()
+        bufs = {"mean": np.empty((n, 3)), "cov": np.empty((n, 3, 3)), "norm": np.empty((n, 3)),
+                "icov": np.empty((n, 3, 3)), "counts": np.empty(n, np.int64), "keys": np.empty(n, np.int64)}
+        nv = C.c_int64(0)
+        args = [_ptr(bufs[k]) if k in names else None for k in ("mean", "cov", "norm", "icov", "counts", "keys")]
+        check(lib().pcr_target_voxels_get(self.handle, C.byref(nv), *args))
+        return {k: bufs[k] for k in names}
+
+    def index_info(self):
+        cell, occ, n = C.c_double(0), C.c_int64(0), C.c_int64(0)
+        dims = np.zeros(3, np.int64)
+        check(lib().pcr_target_index_info(self.handle, C.byref(cell), dims, C.byref(occ), C.byref(n)))
+        return {"cell": cell.value, "dims": tuple(int(d) for d in dims), "occupied": occ.value, "n": n.value}
+
+    def nn_query(self, q, r_max=np.inf):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        m = q.shape[0]
+        idx = np.empty(m, np.int64)
+        if self.is_voxel:
+            dist = np.empty(m, np.float64)
+            check(lib().pcr_nn_query_f64(self.handle, q, m, float(r_max), dist, idx))
+        else:
+            dist = np.empty(m, np.float32)
+            check(lib().pcr_nn_query(self.handle, q, m, float(r_max), dist, idx))
+        return dist, idx
+
+    def knn_query(self, q, k):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        m = q.shape[0]
+        dist = np.empty((m, k), np.float32)
+        idx = np.empty((m, k), np.int64)
+        check(lib().pcr_knn_query(self.handle, q, m, int(k), dist, idx))
+        return dist, idx
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().pcr_target_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Scan:
+    """pcr_scan handle: the float32 scan, uploaded and Morton-sorted once per align()."""
+
+    def __init__(self, ctx, xyz=None, flags=0, device_ptr=None, n=None):
+        self.ctx = ctx
+        h = _vp()
+        if device_ptr is not None:
+            check(lib().pcr_scan_create_device(ctx.handle, _vp(device_ptr), int(n), int(flags), C.byref(h)))
+            self.n = int(n)
+        else:
+            xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+            if xyz.ndim != 2 or xyz.shape[1] != 3:
+                raise ValueError("scan must have shape (N, 3)")
+            check(lib().pcr_scan_create(ctx.handle, _ptr(xyz), xyz.shape[0], int(flags), C.byref(h)))
+            self.n = xyz.shape[0]
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().pcr_scan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def linearize(target, scan, kind, T, max_dist, flags=FLAG_ICP_RR_QUIRK):
+    """One pass of the hot path -> the 29 sums (see include/pcr.h)."""
+    out = np.zeros(29)
+    T = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+    check(lib().pcr_linearize(target.handle, scan.handle, int(kind), T, float(max_dist), int(flags), out))
+    return out
+
+
+def align(target, scan, kind, T_init, max_iter, tol, max_dist, flags=FLAG_ICP_RR_QUIRK, want_trace=False):
+    """pcr_align: the whole Gauss-Newton loop behind the boundary."""
+    T0 = np.ascontiguousarray(T_init, dtype=np.float64).reshape(16)
+    T = np.zeros(16)
+    iters = C.c_int(0)
+    trace = np.zeros((max(int(max_iter), 1), 45)) if want_trace else None
+    check(lib().pcr_align(target.handle, scan.handle, int(kind), T0, int(max_iter), float(tol), float(max_dist),
+                          int(flags), T, C.byref(iters), _ptr(trace)))
+    T = T.reshape(4, 4)
+    if want_trace:
+        return T, iters.value, trace[:iters.value]
+    return T, iters.value
+
+
+def unpack29(out):
+    """29 sums -> (H 6x6 symmetric, g 6, e2, count)."""
+    H = np.zeros((6, 6))
+    H[np.triu_indices(6)] = out[:21]
+    H = H + np.triu(H, 1).T
+    return H, np.array(out[21:27]), float(out[27]), int(round(out[28]))

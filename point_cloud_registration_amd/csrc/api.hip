@@ -1,0 +1,511 @@
+// C-ABI entry points of libpcr_hip.so (declared in include/pcr.h): contexts, targets, scans,
+// the hot path, the behind-the-boundary Gauss-Newton driver, the KD-tree seam, profiling.
+#include <math.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+
+#include "pcr_internal.h"
+
+// ---- errors ---------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+void pcr_set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+extern "C" const char *pcr_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char *pcr_version(void) { return "pcr-hip 0.1 (gfx950)"; }
+
+extern "C" pcr_status pcr_device_count(int *count) {
+    PCR_REQUIRE(count, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { n = 0; (void)hipGetLastError(); }
+    *count = n;
+    return PCR_OK;
+}
+
+// ---- context --------------------------------------------------------------------------------
+extern "C" pcr_status pcr_context_create(int device, pcr_context **out) {
+    PCR_REQUIRE(out, "out is NULL");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) {
+        pcr_set_error("device %d out of range (%d visible)", device, n);
+        return PCR_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(device));
+    pcr_context *ctx = new pcr_context();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->variant = 1;      // measured on MI355X: NN kernel + reduce kernel beats the fused kernel (occupancy)
+    const char *v = getenv("PCR_VARIANT");
+    if (v) ctx->variant = atoi(v) == 0 ? 0 : 1;
+    *out = ctx;
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_context_destroy(pcr_context *ctx) {
+    if (!ctx) return PCR_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    pcr_comm_destroy(ctx);
+    for (auto &e : ctx->prof_events) { (void)hipEventDestroy(e.start); (void)hipEventDestroy(e.stop); }
+    for (auto &e : ctx->prof_free) { (void)hipEventDestroy(e.start); (void)hipEventDestroy(e.stop); }
+    if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+    if (ctx->d_out) (void)hipFree(ctx->d_out);
+    if (ctx->h_out) (void)hipHostFree(ctx->h_out);
+    if (ctx->d_nn_j) (void)hipFree(ctx->d_nn_j);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_context_stream(pcr_context *ctx, void **stream) {
+    PCR_REQUIRE(ctx && stream, "NULL argument");
+    *stream = (void *)ctx->stream;
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_context_synchronize(pcr_context *ctx) {
+    PCR_REQUIRE(ctx, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_set_variant(pcr_context *ctx, int variant) {
+    PCR_REQUIRE(ctx, "ctx is NULL");
+    PCR_REQUIRE(variant == 0 || variant == 1, "variant must be 0 or 1");
+    ctx->variant = variant;
+    return PCR_OK;
+}
+
+// ---- profiling: HIP events around every hot-path launch, on the launch stream ------------------
+void pcr_prof_begin(pcr_context *ctx, int kernel, ProfEvent *ev) {
+    ev->kernel = -1;
+    if (!ctx->prof_on) return;
+    if (!ctx->prof_free.empty()) {
+        *ev = ctx->prof_free.back();
+        ctx->prof_free.pop_back();
+    } else {
+        if (hipEventCreate(&ev->start) != hipSuccess) return;
+        if (hipEventCreate(&ev->stop) != hipSuccess) { (void)hipEventDestroy(ev->start); return; }
+    }
+    ev->kernel = kernel;
+    (void)hipEventRecord(ev->start, ctx->stream);
+}
+
+void pcr_prof_end(pcr_context *ctx, ProfEvent *ev) {
+    if (ev->kernel < 0) return;
+    (void)hipEventRecord(ev->stop, ctx->stream);
+    ctx->prof_events.push_back(*ev);
+}
+
+static void prof_drain(pcr_context *ctx) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &e : ctx->prof_events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.start, e.stop) == hipSuccess) {
+            ctx->prof_launches[e.kernel] += 1;
+            ctx->prof_ms[e.kernel] += ms;
+        }
+        ctx->prof_free.push_back(e);
+    }
+    ctx->prof_events.clear();
+}
+
+extern "C" pcr_status pcr_profile_enable(pcr_context *ctx, int on) {
+    PCR_REQUIRE(ctx, "ctx is NULL");
+    if (!on) prof_drain(ctx);
+    ctx->prof_on = on != 0;
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_profile_reset(pcr_context *ctx) {
+    PCR_REQUIRE(ctx, "ctx is NULL");
+    prof_drain(ctx);
+    for (int i = 0; i < PCR_K_COUNT; ++i) { ctx->prof_launches[i] = 0; ctx->prof_ms[i] = 0; }
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_profile_read(pcr_context *ctx, int64_t launches[PCR_K_COUNT], double total_ms[PCR_K_COUNT]) {
+    PCR_REQUIRE(ctx && launches && total_ms, "NULL argument");
+    prof_drain(ctx);
+    for (int i = 0; i < PCR_K_COUNT; ++i) { launches[i] = ctx->prof_launches[i]; total_ms[i] = ctx->prof_ms[i]; }
+    return PCR_OK;
+}
+
+// ---- small helpers ---------------------------------------------------------------------------
+template <typename T>
+static pcr_status upload(pcr_context *ctx, const T *host, size_t count, T **dev) {
+    *dev = nullptr;
+    HIP_TRY(hipMalloc(dev, sizeof(T) * (count ? count : 1)));
+    if (count) {
+        HIP_TRY(hipMemcpyAsync(*dev, host, sizeof(T) * count, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return PCR_OK;
+}
+
+static void target_free(pcr_target *t) {
+    if (!t) return;
+    void *ptrs[] = {t->cell_start, t->pts, t->normals, t->means, t->vnorm, t->vicov,
+                    t->st_mean, t->st_cov, t->st_norm, t->st_icov, t->st_counts, t->st_keys};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    delete t;
+}
+
+// ---- point targets ---------------------------------------------------------------------------
+static pcr_status points_create_common(pcr_context *ctx, const float *d_xyz, int64_t n, const float *d_normals,
+                                       float cell_hint, pcr_target **out) {
+    pcr_target *t = new pcr_target();
+    t->ctx = ctx; t->is_voxel = 0; t->n = n;
+    pcr_status s = pcr_build_point_grid(ctx, d_xyz, n, cell_hint, t);
+    if (s == PCR_OK && d_normals) {
+        hipError_t e = hipMalloc(&t->normals, sizeof(float4) * (size_t)(n ? n : 1));
+        if (e != hipSuccess) { pcr_set_error("hipMalloc normals: %s", hipGetErrorString(e)); s = PCR_ERR_HIP; }
+        else s = pcr_permute_rows_f32(ctx, d_normals, n, 3, t->pts, t->normals);
+        if (s == PCR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s = PCR_ERR_HIP;
+    }
+    if (s != PCR_OK) { target_free(t); return s; }
+    *out = t;
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_target_points_create(pcr_context *ctx, const float *xyz, int64_t n,
+                                               const float *normals_or_null, float cell_hint, pcr_target **out) {
+    PCR_REQUIRE(ctx && out, "NULL argument");
+    PCR_REQUIRE(n >= 0 && (xyz || n == 0), "bad point array");
+    HIP_TRY(hipSetDevice(ctx->device));
+    float *d_xyz = nullptr, *d_nrm = nullptr;
+    PCR_TRY(upload<float>(ctx, xyz, (size_t)n * 3, &d_xyz));
+    pcr_status s = PCR_OK;
+    if (normals_or_null) s = upload<float>(ctx, normals_or_null, (size_t)n * 3, &d_nrm);
+    if (s == PCR_OK) s = points_create_common(ctx, d_xyz, n, d_nrm, cell_hint, out);
+    (void)hipFree(d_xyz);
+    if (d_nrm) (void)hipFree(d_nrm);
+    return s;
+}
+
+extern "C" pcr_status pcr_target_points_create_device(pcr_context *ctx, const float *d_xyz, int64_t n,
+                                                      const float *d_normals_or_null, float cell_hint,
+                                                      pcr_target **out) {
+    PCR_REQUIRE(ctx && out, "NULL argument");
+    PCR_REQUIRE(n >= 0 && (d_xyz || n == 0), "bad point array");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return points_create_common(ctx, d_xyz, n, d_normals_or_null, cell_hint, out);
+}
+
+extern "C" pcr_status pcr_target_set_normals(pcr_target *t, const float *normals) {
+    PCR_REQUIRE(t && normals, "NULL argument");
+    PCR_REQUIRE(!t->is_voxel, "normals belong to point targets");
+    pcr_context *ctx = t->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    float *d_nrm = nullptr;
+    PCR_TRY(upload<float>(ctx, normals, (size_t)t->n * 3, &d_nrm));
+    if (!t->normals) HIP_TRY(hipMalloc(&t->normals, sizeof(float4) * (size_t)(t->n ? t->n : 1)));
+    pcr_status s = pcr_permute_rows_f32(ctx, d_nrm, t->n, 3, t->pts, t->normals);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_nrm);
+    return s;
+}
+
+__global__ void __launch_bounds__(256) k_unpermute_normals(const float4 *__restrict__ nrm, const PtF *__restrict__ pts,
+                                                           int64_t n, float *out) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const size_t i = __float_as_uint(pts[j].w);
+    const float4 v = nrm[j];
+    out[3 * i] = v.x; out[3 * i + 1] = v.y; out[3 * i + 2] = v.z;
+}
+
+extern "C" pcr_status pcr_target_get_normals(pcr_target *t, float *normals_out) {
+    PCR_REQUIRE(t && normals_out, "NULL argument");
+    if (t->is_voxel || !t->normals) { pcr_set_error("target has no per-point normals"); return PCR_ERR_NO_TARGET; }
+    pcr_context *ctx = t->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (t->n == 0) return PCR_OK;
+    float *d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_out, sizeof(float) * 3 * (size_t)t->n));
+    hipLaunchKernelGGL(k_unpermute_normals, dim3((unsigned)((t->n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       t->normals, t->pts, t->n, d_out);
+    HIP_TRY(hipMemcpyAsync(normals_out, d_out, sizeof(float) * 3 * (size_t)t->n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d_out));
+    return PCR_OK;
+}
+
+// ---- voxel targets from statistics -----------------------------------------------------------
+pcr_status pcr_voxel_target_finish(pcr_context *ctx, pcr_target *t, double voxel_size) {
+    // t->st_mean (+ st_norm, st_icov) are on the device in key order: build the centroid grid and
+    // the cell-sorted copies the kernels gather from.
+    t->voxel_size = voxel_size;
+    PCR_TRY(pcr_build_centroid_grid(ctx, t->st_mean, t->n, voxel_size, t));
+    const size_t nn = (size_t)(t->n ? t->n : 1);
+    if (t->st_norm) {
+        HIP_TRY(hipMalloc(&t->vnorm, sizeof(double) * 3 * nn));
+        const int cols[3] = {0, 1, 2};
+        PCR_TRY(pcr_permute_rows_f64(ctx, t->st_norm, t->n, 3, cols, 3, t->means, t->vnorm));
+    }
+    if (t->st_icov) {
+        HIP_TRY(hipMalloc(&t->vicov, sizeof(double) * 6 * nn));
+        const int cols[6] = {0, 1, 2, 4, 5, 8};
+        PCR_TRY(pcr_permute_rows_f64(ctx, t->st_icov, t->n, 9, cols, 6, t->means, t->vicov));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_target_voxels_create_from_stats(pcr_context *ctx, const double *mean,
+                                                          const double *norm_or_null, const double *icov_or_null,
+                                                          int64_t n_v, double voxel_size, pcr_target **out) {
+    PCR_REQUIRE(ctx && out, "NULL argument");
+    PCR_REQUIRE(n_v >= 0 && (mean || n_v == 0), "bad mean array");
+    PCR_REQUIRE(voxel_size > 0, "voxel_size must be positive");
+    HIP_TRY(hipSetDevice(ctx->device));
+    pcr_target *t = new pcr_target();
+    t->ctx = ctx; t->is_voxel = 1; t->n = n_v;
+    pcr_status s = upload<double>(ctx, mean, (size_t)n_v * 3, &t->st_mean);
+    if (s == PCR_OK && norm_or_null) s = upload<double>(ctx, norm_or_null, (size_t)n_v * 3, &t->st_norm);
+    if (s == PCR_OK && icov_or_null) s = upload<double>(ctx, icov_or_null, (size_t)n_v * 9, &t->st_icov);
+    if (s == PCR_OK) s = pcr_voxel_target_finish(ctx, t, voxel_size);
+    if (s != PCR_OK) { target_free(t); return s; }
+    *out = t;
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_target_voxels_get(pcr_target *t, int64_t *n_v, double *mean, double *cov, double *norm,
+                                            double *icov, int64_t *counts, int64_t *keys) {
+    PCR_REQUIRE(t && n_v, "NULL argument");
+    PCR_REQUIRE(t->is_voxel, "not a voxel target");
+    pcr_context *ctx = t->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    *n_v = t->n;
+    const size_t n = (size_t)t->n;
+    struct { void *dst; const void *src; size_t bytes; const char *what; } c[] = {
+        {mean, t->st_mean, n * 3 * 8, "mean"}, {cov, t->st_cov, n * 9 * 8, "cov"}, {norm, t->st_norm, n * 3 * 8, "norm"},
+        {icov, t->st_icov, n * 9 * 8, "icov"}, {counts, t->st_counts, n * 8, "counts"}, {keys, t->st_keys, n * 8, "keys"}};
+    for (auto &e : c) {
+        if (!e.dst) continue;
+        if (!e.src) { pcr_set_error("voxel target does not hold '%s'", e.what); return PCR_ERR_NO_TARGET; }
+        if (e.bytes) HIP_TRY(hipMemcpyAsync(e.dst, e.src, e.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_target_size(pcr_target *t, int64_t *n) {
+    PCR_REQUIRE(t && n, "NULL argument");
+    *n = t->n;
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_target_index_info(pcr_target *t, double *cell, int64_t dims[3], int64_t *occupied, int64_t *n) {
+    PCR_REQUIRE(t, "NULL argument");
+    if (cell) *cell = t->is_voxel ? t->gd.h : (double)t->gf.h;
+    if (dims) {
+        dims[0] = t->is_voxel ? t->gd.nx : t->gf.nx;
+        dims[1] = t->is_voxel ? t->gd.ny : t->gf.ny;
+        dims[2] = t->is_voxel ? t->gd.nz : t->gf.nz;
+    }
+    if (occupied) *occupied = t->occupied;
+    if (n) *n = t->n;
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_target_destroy(pcr_target *t) {
+    if (!t) return PCR_OK;
+    (void)hipSetDevice(t->ctx->device);
+    (void)hipStreamSynchronize(t->ctx->stream);
+    target_free(t);
+    return PCR_OK;
+}
+
+// ---- scan ------------------------------------------------------------------------------------
+extern "C" pcr_status pcr_scan_create_device(pcr_context *ctx, const float *d_xyz, int64_t n, unsigned flags,
+                                             pcr_scan **out) {
+    PCR_REQUIRE(ctx && out, "NULL argument");
+    PCR_REQUIRE(n >= 0 && (d_xyz || n == 0), "bad scan array");
+    pcr_scan *s = new pcr_scan();
+    s->ctx = ctx;
+    pcr_status st = pcr_sort_scan(ctx, d_xyz, n, flags, s);
+    if (st != PCR_OK) { pcr_scan_destroy(s); return st; }
+    *out = s;
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_scan_create(pcr_context *ctx, const float *xyz, int64_t n, unsigned flags, pcr_scan **out) {
+    PCR_REQUIRE(ctx && out, "NULL argument");
+    PCR_REQUIRE(n >= 0 && (xyz || n == 0), "bad scan array");
+    HIP_TRY(hipSetDevice(ctx->device));
+    float *d_xyz = nullptr;
+    PCR_TRY(upload<float>(ctx, xyz, (size_t)n * 3, &d_xyz));
+    pcr_status s = pcr_scan_create_device(ctx, d_xyz, n, flags, out);
+    (void)hipFree(d_xyz);
+    return s;
+}
+
+extern "C" pcr_status pcr_scan_size(pcr_scan *s, int64_t *n) {
+    PCR_REQUIRE(s && n, "NULL argument");
+    *n = s->n;
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_scan_destroy(pcr_scan *s) {
+    if (!s) return PCR_OK;
+    if (s->ctx) { (void)hipSetDevice(s->ctx->device); (void)hipStreamSynchronize(s->ctx->stream); }
+    if (s->x) (void)hipFree(s->x);
+    if (s->y) (void)hipFree(s->y);
+    if (s->z) (void)hipFree(s->z);
+    delete s;
+    return PCR_OK;
+}
+
+// ---- hot path --------------------------------------------------------------------------------
+extern "C" pcr_status pcr_linearize(pcr_target *t, pcr_scan *s, int kind, const double T[16], double max_dist,
+                                    unsigned flags, double out[29]) {
+    PCR_REQUIRE(t && s && T && out, "NULL argument");
+    return pcr_run_linearize(t, s, kind, T, max_dist, flags, out);
+}
+
+// ---- Gauss-Newton driver behind the boundary (registration.py:71-113) -------------------------
+// numpy.linalg.solve: LU with partial pivoting, exact-zero pivot = singular (quirk Q7)
+static int solve6(const double H[36], const double g[6], double x[6]) {
+    double A[6][7];
+    for (int i = 0; i < 6; ++i) { for (int j = 0; j < 6; ++j) A[i][j] = H[6 * i + j]; A[i][6] = g[i]; }
+    for (int c = 0; c < 6; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 6; ++r) if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
+        if (A[piv][c] == 0.0) return 1;
+        if (piv != c) for (int j = 0; j < 7; ++j) { const double tmp = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = tmp; }
+        for (int r = c + 1; r < 6; ++r) {
+            const double f = A[r][c] / A[c][c];
+            for (int j = c; j < 7; ++j) A[r][j] -= f * A[c][j];
+        }
+    }
+    for (int i = 5; i >= 0; --i) {
+        double v = A[i][6];
+        for (int j = i + 1; j < 6; ++j) v -= A[i][j] * x[j];
+        x[i] = v / A[i][i];
+    }
+    return 0;
+}
+
+// math_tools.py:80-98: first-order I + skew(w) when w.w <= 1e-5 (quirk Q3), Rodrigues otherwise
+static void exp_so3(const double w[3], double R[9]) {
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+    if (th2 <= 1e-5) {
+        for (int i = 0; i < 9; ++i) R[i] = W[i];
+    } else {
+        const double th = sqrt(th2), sn = sin(th), omc = 1.0 - cos(th);
+        double K[9];
+        for (int i = 0; i < 9; ++i) K[i] = W[i] / th;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double kk = 0;
+                for (int k = 0; k < 3; ++k) kk += K[3 * i + k] * K[3 * k + j];
+                R[3 * i + j] = sn * K[3 * i + j] + omc * kk;
+            }
+    }
+    R[0] += 1; R[4] += 1; R[8] += 1;
+}
+
+// math_tools.py:101-108: T <- T @ [exp(w), v; 0 1] (quirk Q2)
+static void se3_plus(double T[16], const double dx[6]) {
+    double dR[9];
+    exp_so3(dx + 3, dR);
+    const double D[16] = {dR[0], dR[1], dR[2], dx[0], dR[3], dR[4], dR[5], dx[1], dR[6], dR[7], dR[8], dx[2], 0, 0, 0, 1};
+    double r[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double v = 0;
+            for (int k = 0; k < 4; ++k) v += T[4 * i + k] * D[4 * k + j];
+            r[4 * i + j] = v;
+        }
+    memcpy(T, r, sizeof r);
+}
+
+extern "C" pcr_status pcr_align(pcr_target *t, pcr_scan *s, int kind, const double T_init[16], int max_iter, double tol,
+                                double max_dist, unsigned flags, double T_out[16], int *iterations,
+                                double *trace_or_null) {
+    PCR_REQUIRE(t && s && T_init && T_out, "NULL argument");
+    double T[16];
+    memcpy(T, T_init, sizeof T);
+    int it = 0;
+    for (; it < max_iter; ++it) {
+        double o[29];
+        PCR_TRY(pcr_run_linearize(t, s, kind, T, max_dist, flags, o));
+        if (trace_or_null) {
+            memcpy(trace_or_null + (size_t)it * 45, T, 16 * sizeof(double));
+            memcpy(trace_or_null + (size_t)it * 45 + 16, o, 29 * sizeof(double));
+        }
+        double H[36], g[6], dx[6];
+        int p = 0;
+        for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) { H[6 * i + j] = o[p]; H[6 * j + i] = o[p]; ++p; }
+        for (int i = 0; i < 6; ++i) g[i] = o[21 + i];
+        if (solve6(H, g, dx)) {
+            pcr_set_error("Singular matrix (correspondences: %.0f)", o[28]);
+            if (iterations) *iterations = it + 1;
+            memcpy(T_out, T, sizeof T);
+            return PCR_ERR_SINGULAR;
+        }
+        double nrm = 0;
+        for (int i = 0; i < 6; ++i) { dx[i] = -dx[i]; nrm += dx[i] * dx[i]; }
+        if (sqrt(nrm) < tol) { ++it; break; }     // registration.py:106-108: test precedes the update (Q4)
+        se3_plus(T, dx);
+    }
+    if (iterations) *iterations = it;
+    memcpy(T_out, T, sizeof T);
+    return PCR_OK;
+}
+
+// ---- KD-tree seam ----------------------------------------------------------------------------
+static pcr_status nn_query_common(pcr_target *t, const float *q, int64_t m, double r_max, void *dist, int64_t *idx, int f64) {
+    PCR_REQUIRE(t && (q || m == 0) && (dist || m == 0) && (idx || m == 0), "NULL argument");
+    pcr_context *ctx = t->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (m == 0) return PCR_OK;
+    float *d_q = nullptr;
+    PCR_TRY(upload<float>(ctx, q, (size_t)m * 3, &d_q));
+    void *d_dist = nullptr;
+    int64_t *d_idx = nullptr;
+    const size_t ds = f64 ? 8 : 4;
+    pcr_status s = PCR_OK;
+    if (hipMalloc(&d_dist, ds * (size_t)m) != hipSuccess || hipMalloc(&d_idx, 8 * (size_t)m) != hipSuccess) {
+        pcr_set_error("hipMalloc failed for %lld query results", (long long)m);
+        s = PCR_ERR_NOMEM;
+    }
+    if (s == PCR_OK) s = pcr_run_nn(t, d_q, m, r_max, d_dist, d_idx, f64);
+    if (s == PCR_OK) {
+        if (hipMemcpyAsync(dist, d_dist, ds * (size_t)m, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(idx, d_idx, 8 * (size_t)m, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            pcr_set_error("copy-back of query results failed: %s", hipGetErrorString(hipGetLastError()));
+            s = PCR_ERR_HIP;
+        }
+    }
+    (void)hipFree(d_q);
+    if (d_dist) (void)hipFree(d_dist);
+    if (d_idx) (void)hipFree(d_idx);
+    return s;
+}
+
+extern "C" pcr_status pcr_nn_query(pcr_target *t, const float *q, int64_t m, float r_max, float *dist, int64_t *idx) {
+    return nn_query_common(t, q, m, (double)r_max, dist, idx, 0);
+}
+
+extern "C" pcr_status pcr_nn_query_f64(pcr_target *t, const float *q, int64_t m, double r_max, double *dist, int64_t *idx) {
+    return nn_query_common(t, q, m, r_max, dist, idx, 1);
+}

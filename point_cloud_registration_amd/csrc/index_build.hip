@@ -1,0 +1,360 @@
+// Index construction (set_target side, once per target / once per align for the scan):
+//   - dense cell grid over the target points      (replaces the pykdtree build, icp.py:20,
+//     plane_icp.py:22, reference kdtree.py:18-21)
+//   - dense cell grid over the kept voxel centroids (replaces KDTree(means), voxel.py:165)
+//   - Morton sort of the scan (registration.py:83 casts the scan once per align; here it is
+//     also uploaded and ordered once, the per-iteration kernels then stream it)
+//
+// Sorting and prefix sums use rocPRIM through hipCUB (device-wide radix sort / scan); the
+// kernels around them are hand-written.  Everything runs on the context's stream.
+#include <hipcub/hipcub.hpp>
+
+#include <math.h>
+
+#include "pcr_internal.h"
+
+// ---- bounding box ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned f2ord(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+static inline float ord2f(unsigned u) {
+    const unsigned v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f;
+    memcpy(&f, &v, 4);
+    return f;
+}
+
+// box[0..2] = min (ordered-uint encoding), box[3..5] = max
+template <typename T>
+__global__ void __launch_bounds__(256) k_bbox(const T *__restrict__ xyz, int64_t n, unsigned *box) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            // round outward when narrowing float64 centroids
+            const T v = xyz[3 * i + a];
+            float fl = (float)v, fh = (float)v;
+            if ((T)fl > v) fl = nextafterf(fl, -INFINITY);
+            if ((T)fh < v) fh = nextafterf(fh, INFINITY);
+            lo[a] = fminf(lo[a], fl); hi[a] = fmaxf(hi[a], fh);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int off = 32; off >= 1; off >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, 64));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&box[a], f2ord(lo[a]));
+            atomicMax(&box[3 + a], f2ord(hi[a]));
+        }
+    }
+}
+
+template <typename T>
+static pcr_status device_bbox(pcr_context *ctx, const T *d_xyz, int64_t n, float lo[3], float hi[3]) {
+    unsigned *d_box = nullptr;
+    HIP_TRY(hipMalloc(&d_box, 6 * sizeof(unsigned)));
+    unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    HIP_TRY(hipMemcpyAsync(d_box, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    if (n > 0) {
+        int64_t nb = (n + 255) / 256;
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(k_bbox<T>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_xyz, n, d_box);
+    }
+    unsigned h[6];
+    HIP_TRY(hipMemcpyAsync(h, d_box, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d_box));
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = n > 0 ? ord2f(h[a]) : 0.f;
+        hi[a] = n > 0 ? ord2f(h[3 + a]) : 0.f;
+    }
+    return PCR_OK;
+}
+
+// ---- cell ids, histogram -----------------------------------------------------------------
+template <typename Real>
+__device__ __forceinline__ uint32_t cell_of(const Geom<Real> &g, Real x, Real y, Real z) {
+    int cx = (int)floor((x - g.ox) * g.inv_h), cy = (int)floor((y - g.oy) * g.inv_h), cz = (int)floor((z - g.oz) * g.inv_h);
+    cx = min(max(cx, 0), g.nx - 1); cy = min(max(cy, 0), g.ny - 1); cz = min(max(cz, 0), g.nz - 1);
+    return (uint32_t)(((size_t)cz * g.ny + cy) * g.nx + cx);
+}
+
+template <typename Real, typename T>
+__global__ void __launch_bounds__(256) k_cell_ids(const T *__restrict__ xyz, int64_t n, Geom<Real> g,
+                                                  uint32_t *cell_id, uint32_t *idx, uint32_t *counts) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = cell_of<Real>(g, (Real)xyz[3 * i], (Real)xyz[3 * i + 1], (Real)xyz[3 * i + 2]);
+    if (cell_id) { cell_id[i] = c; idx[i] = (uint32_t)i; }
+    atomicAdd(&counts[c], 1u);
+}
+
+__global__ void __launch_bounds__(256) k_count_nonzero(const uint32_t *__restrict__ counts, int64_t n, unsigned long long *out) {
+    unsigned local = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) local += counts[i] != 0;
+    for (int off = 32; off >= 1; off >>= 1) local += __shfl_xor(local, off, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, (unsigned long long)local);
+}
+
+__global__ void __launch_bounds__(256) k_gather_f32(const float *__restrict__ xyz, const uint32_t *__restrict__ order,
+                                                    int64_t n, PtF *out) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t i = order[j];
+    out[j] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], __uint_as_float(i));
+}
+
+__global__ void __launch_bounds__(256) k_gather_f64(const double *__restrict__ xyz, const uint32_t *__restrict__ order,
+                                                    int64_t n, PtD *out) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t i = order[j];
+    out[j] = make_double4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2],
+                          __longlong_as_double((long long)i));
+}
+
+template <typename Real>
+static bool make_geom(const float lo[3], const float hi[3], double h, Geom<Real> *g, double *ncells) {
+    g->ox = (Real)lo[0]; g->oy = (Real)lo[1]; g->oz = (Real)lo[2];
+    g->h = (Real)h; g->inv_h = (Real)(1.0 / h);
+    double dims[3];
+    for (int a = 0; a < 3; ++a) dims[a] = floor(((double)hi[a] - (double)lo[a]) / h) + 2.0;
+    *ncells = dims[0] * dims[1] * dims[2];
+    if (dims[0] > 2.0e9 || dims[1] > 2.0e9 || dims[2] > 2.0e9) return false;
+    g->nx = (int)dims[0]; g->ny = (int)dims[1]; g->nz = (int)dims[2];
+    double mag = 0;
+    for (int a = 0; a < 3; ++a) { mag = fmax(mag, fabs((double)lo[a])); mag = fmax(mag, fabs((double)hi[a])); }
+    const double eps = sizeof(Real) == 4 ? 1.2e-7 : 2.3e-16;
+    g->slack = (Real)(16.0 * eps * (mag + h) + 1e-30);
+    return true;
+}
+
+// counts -> exclusive prefix (cell_start has ncells+1 entries; counts[ncells] must be 0)
+static pcr_status exclusive_scan_u32(pcr_context *ctx, uint32_t *d_inout, int64_t n) {
+    size_t tmp_bytes = 0;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_inout, d_inout, (int)n, ctx->stream));
+    void *tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, d_inout, d_inout, (int)n, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(tmp));
+    return PCR_OK;
+}
+
+template <typename K>
+static pcr_status sort_pairs(pcr_context *ctx, K *keys_in, K *keys_out, uint32_t *vals_in, uint32_t *vals_out, int64_t n,
+                             int end_bit) {
+    size_t tmp_bytes = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, end_bit,
+                                               ctx->stream));
+    void *tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, end_bit,
+                                               ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(tmp));
+    return PCR_OK;
+}
+
+static int bits_for(double ncells) {
+    int b = 1;
+    while (b < 32 && ldexp(1.0, b) < ncells) ++b;
+    return b;
+}
+
+// Shared build: pick h (auto: average occupancy of the occupied cells in [3, 10]), histogram,
+// prefix, stable radix sort by cell id, gather.
+template <typename Real, typename T, typename PT>
+static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double h, bool auto_h, Geom<Real> *geom,
+                             uint32_t **cell_start_out, PT **pts_out, int64_t *occupied_out) {
+    PCR_REQUIRE(n < ((int64_t)1 << 31), "at most 2^31-1 points per target");
+    HIP_TRY(hipSetDevice(ctx->device));
+    float lo[3], hi[3];
+    PCR_TRY(device_bbox<T>(ctx, d_xyz, n, lo, hi));
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const double max_cells = fmin(1.0e9, (double)free_b / 4.0 / 8.0);   // cell_start may take 1/8 of free HBM
+
+    uint32_t *d_counts = nullptr;
+    unsigned long long *d_nz = nullptr;
+    HIP_TRY(hipMalloc(&d_nz, sizeof(unsigned long long)));
+    double ncells = 0;
+    int64_t occupied = 0;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    int dir = 0;                  // auto cell size moves in one direction only: -1 shrinking, +1 growing
+    bool capped = false;          // hit the memory cap: cannot shrink further
+    for (int iter = 0; iter < 16; ++iter) {
+        Geom<Real> g;
+        while (!make_geom<Real>(lo, hi, h, &g, &ncells) || ncells > max_cells) { h *= 2.0; capped = true; }
+        if (d_counts) { HIP_TRY(hipFree(d_counts)); d_counts = nullptr; }
+        HIP_TRY(hipMalloc(&d_counts, sizeof(uint32_t) * ((size_t)ncells + 1)));
+        HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * ((size_t)ncells + 1), ctx->stream));
+        if (n > 0)
+            hipLaunchKernelGGL((k_cell_ids<Real, T>), dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, g,
+                               (uint32_t *)nullptr, (uint32_t *)nullptr, d_counts);
+        HIP_TRY(hipMemsetAsync(d_nz, 0, sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(k_count_nonzero, dim3(1024), dim3(256), 0, ctx->stream, d_counts, (int64_t)ncells, d_nz);
+        unsigned long long nz = 0;
+        HIP_TRY(hipMemcpyAsync(&nz, d_nz, sizeof nz, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        occupied = (int64_t)nz;
+        if (!auto_h || n == 0) break;
+        const double occ = (double)n / (double)(occupied > 0 ? occupied : 1);
+        if (occ > 10.0 && dir <= 0 && !capped) { h *= 0.5; dir = -1; continue; }
+        if (occ < 2.5 && dir >= 0) { h *= 2.0; dir = 1; continue; }
+        break;
+    }
+    HIP_TRY(hipFree(d_nz));
+    // with the final h: ids + fresh histogram
+    Geom<Real> g;
+    make_geom<Real>(lo, hi, h, &g, &ncells);
+    while (ncells > max_cells) { h *= 2.0; make_geom<Real>(lo, hi, h, &g, &ncells); }
+    *geom = g;
+    if (d_counts) HIP_TRY(hipFree(d_counts));
+    HIP_TRY(hipMalloc(&d_counts, sizeof(uint32_t) * ((size_t)ncells + 1)));
+    HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * ((size_t)ncells + 1), ctx->stream));
+    uint32_t *d_cid = nullptr, *d_idx = nullptr, *d_cid2 = nullptr, *d_idx2 = nullptr;
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    HIP_TRY(hipMalloc(&d_cid, 4 * nn)); HIP_TRY(hipMalloc(&d_idx, 4 * nn));
+    HIP_TRY(hipMalloc(&d_cid2, 4 * nn)); HIP_TRY(hipMalloc(&d_idx2, 4 * nn));
+    PT *d_pts = nullptr;
+    HIP_TRY(hipMalloc(&d_pts, sizeof(PT) * nn));
+    if (n > 0) {
+        hipLaunchKernelGGL((k_cell_ids<Real, T>), dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, g, d_cid, d_idx, d_counts);
+        PCR_TRY(sort_pairs<uint32_t>(ctx, d_cid, d_cid2, d_idx, d_idx2, n, bits_for(ncells)));
+        if (sizeof(Real) == 4)
+            hipLaunchKernelGGL(k_gather_f32, dim3(nb), dim3(256), 0, ctx->stream, (const float *)d_xyz, d_idx2, n, (PtF *)d_pts);
+        else
+            hipLaunchKernelGGL(k_gather_f64, dim3(nb), dim3(256), 0, ctx->stream, (const double *)d_xyz, d_idx2, n, (PtD *)d_pts);
+    }
+    PCR_TRY(exclusive_scan_u32(ctx, d_counts, (int64_t)ncells + 1));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d_cid)); HIP_TRY(hipFree(d_idx)); HIP_TRY(hipFree(d_cid2)); HIP_TRY(hipFree(d_idx2));
+    // occupied cells for the final geometry
+    *occupied_out = occupied;
+    *cell_start_out = d_counts;
+    *pts_out = d_pts;
+    return PCR_OK;
+}
+
+pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n, float cell_hint, pcr_target *t) {
+    double h = cell_hint > 0 ? (double)cell_hint : 0.5;
+    const char *env = getenv("PCR_GRID_CELL");
+    bool auto_h = !(cell_hint > 0);
+    if (env && atof(env) > 0) { h = atof(env); auto_h = false; }
+    return build_grid<float, float, PtF>(ctx, d_xyz, n, h, auto_h, &t->gf, &t->cell_start, &t->pts, &t->occupied);
+}
+
+pcr_status pcr_build_centroid_grid(pcr_context *ctx, const double *d_mean, int64_t n, double cell, pcr_target *t) {
+    return build_grid<double, double, PtD>(ctx, d_mean, n, cell, false, &t->gd, &t->cell_start, &t->means, &t->occupied);
+}
+
+// ---- row permutations into cell-sorted order -------------------------------------------------
+__global__ void __launch_bounds__(256) k_perm_f32(const float *__restrict__ in, int64_t n, int width,
+                                                  const PtF *__restrict__ pts, float4 *out) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const size_t i = __float_as_uint(pts[j].w);
+    float4 v = make_float4(0, 0, 0, 0);
+    v.x = in[i * width]; v.y = in[i * width + 1]; v.z = in[i * width + 2];
+    out[j] = v;
+}
+
+pcr_status pcr_permute_rows_f32(pcr_context *ctx, const float *d_in, int64_t n, int width, const PtF *pts, float4 *out) {
+    if (n == 0) return PCR_OK;
+    hipLaunchKernelGGL(k_perm_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_in, n, width, pts, out);
+    HIP_TRY(hipGetLastError());
+    return PCR_OK;
+}
+
+struct ColSel { int c[9]; int n; };
+__global__ void __launch_bounds__(256) k_perm_f64(const double *__restrict__ in, int64_t n, int stride, ColSel sel,
+                                                  const PtD *__restrict__ means, double *out) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const size_t i = (size_t)__double_as_longlong(means[j].w);
+    for (int k = 0; k < sel.n; ++k) out[(size_t)j * sel.n + k] = in[i * stride + sel.c[k]];
+}
+
+pcr_status pcr_permute_rows_f64(pcr_context *ctx, const double *d_in, int64_t n, int in_stride, const int *cols,
+                                int ncols, const PtD *means, double *out) {
+    if (n == 0) return PCR_OK;
+    ColSel sel;
+    sel.n = ncols;
+    for (int k = 0; k < ncols; ++k) sel.c[k] = cols[k];
+    hipLaunchKernelGGL(k_perm_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_in, n, in_stride, sel,
+                       means, out);
+    HIP_TRY(hipGetLastError());
+    return PCR_OK;
+}
+
+// ---- scan: Morton order, SoA ------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long spread21(unsigned long long v) {
+    v &= 0x1fffffULL;
+    v = (v | (v << 32)) & 0x1f00000000ffffULL;
+    v = (v | (v << 16)) & 0x1f0000ff0000ffULL;
+    v = (v | (v << 8)) & 0x100f00f00f00f00fULL;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ULL;
+    v = (v | (v << 2)) & 0x1249249249249249ULL;
+    return v;
+}
+
+__global__ void __launch_bounds__(256) k_morton(const float *__restrict__ xyz, int64_t n, float ox, float oy, float oz,
+                                                float scale, unsigned long long *keys, uint32_t *idx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float lim = 2097151.f;
+    const unsigned long long qx = (unsigned long long)fminf(fmaxf((xyz[3 * i] - ox) * scale, 0.f), lim);
+    const unsigned long long qy = (unsigned long long)fminf(fmaxf((xyz[3 * i + 1] - oy) * scale, 0.f), lim);
+    const unsigned long long qz = (unsigned long long)fminf(fmaxf((xyz[3 * i + 2] - oz) * scale, 0.f), lim);
+    keys[i] = spread21(qx) | (spread21(qy) << 1) | (spread21(qz) << 2);
+    idx[i] = (uint32_t)i;
+}
+
+__global__ void __launch_bounds__(256) k_to_soa(const float *__restrict__ xyz, const uint32_t *__restrict__ order, int64_t n,
+                                                float *x, float *y, float *z) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const size_t i = order ? order[j] : (size_t)j;
+    x[j] = xyz[3 * i]; y[j] = xyz[3 * i + 1]; z[j] = xyz[3 * i + 2];
+}
+
+pcr_status pcr_sort_scan(pcr_context *ctx, const float *d_xyz, int64_t n, unsigned flags, pcr_scan *s) {
+    PCR_REQUIRE(n < ((int64_t)1 << 31), "at most 2^31-1 points per scan shard");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    HIP_TRY(hipMalloc(&s->x, 4 * nn)); HIP_TRY(hipMalloc(&s->y, 4 * nn)); HIP_TRY(hipMalloc(&s->z, 4 * nn));
+    s->n = n;
+    if (n == 0) return PCR_OK;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    if (flags & PCR_FLAG_NO_SCAN_SORT) {
+        hipLaunchKernelGGL(k_to_soa, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, (const uint32_t *)nullptr, n, s->x, s->y, s->z);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return PCR_OK;
+    }
+    float lo[3], hi[3];
+    PCR_TRY(device_bbox<float>(ctx, d_xyz, n, lo, hi));
+    float ext = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+    if (!(ext > 0)) ext = 1.f;
+    const float scale = 2097151.f / ext;
+    unsigned long long *k1 = nullptr, *k2 = nullptr;
+    uint32_t *i1 = nullptr, *i2 = nullptr;
+    HIP_TRY(hipMalloc(&k1, 8 * nn)); HIP_TRY(hipMalloc(&k2, 8 * nn));
+    HIP_TRY(hipMalloc(&i1, 4 * nn)); HIP_TRY(hipMalloc(&i2, 4 * nn));
+    hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, lo[0], lo[1], lo[2], scale, k1, i1);
+    PCR_TRY(sort_pairs<unsigned long long>(ctx, k1, k2, i1, i2, n, 63));
+    hipLaunchKernelGGL(k_to_soa, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, i2, n, s->x, s->y, s->z);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(k1)); HIP_TRY(hipFree(k2)); HIP_TRY(hipFree(i1)); HIP_TRY(hipFree(i2));
+    return PCR_OK;
+}

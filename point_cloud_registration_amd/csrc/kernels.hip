@@ -1,0 +1,483 @@
+// Hot-path kernels: transform -> exact NN -> gate -> residual/Jacobian -> 6x6 normal equations.
+//
+// One calc_H_g_e2 of the reference (icp.py:24-57, plane_icp.py:30-69,
+// voxelized_plane_icp.py:23-64, ndt.py:24-57) = k_linearize<KIND> + k_finalize.
+//
+// Data layout in HBM
+//   scan      SoA x[], y[], z[] float32, Morton-sorted once per align()  -> 3 coalesced dword
+//             streams, 12 B/point, neighbouring lanes are neighbouring points in space
+//   target    cell-sorted float4 {x, y, z, orig idx}; normals float4 in the same order;
+//             cell_start u32[ncells+1]   (voxel targets: double4 means, double[3] normals,
+//             double[6] inverse covariances; a few MB, L2-resident)
+//   output    per-block partial sums [nblocks][32] double, folded in fixed order by k_finalize
+//             (deterministic: no floating-point atomics anywhere)
+//
+// Roofline: HBM-bound gather/stream work, no dense contraction -> no MFMA.  Algorithmic bytes
+// per scan point: ICP 24, PlaneICP 36, VPlaneICP 36, NDT 48.
+//
+// Launch: 256-thread blocks (4 waves of 64).  Block b works on the contiguous chunk
+// v = (b % 8) * (nblocks / 8) + b / 8 of the sorted scan, so each of the 8 XCDs (block b runs
+// on XCD b % 8) sweeps one contiguous region of space and its private 4 MiB L2 holds that
+// region's target cells.  Per-lane accumulators are float64 (H entries reach 1e11 at 1e8
+// points, float32 would lose the 1e-5 parity bar); the 32 sums are folded across the wave with
+// a halving butterfly (32 shuffles instead of 32 x 6), then across waves through LDS.
+#include "nn_device.h"
+
+struct LinArgs {
+    // scan
+    const float *sx, *sy, *sz;
+    int64_t n;
+    // point target
+    Geom<float> gf;
+    const PtF *pts;
+    const float4 *normals;
+    // voxel target
+    Geom<double> gd;
+    const PtD *means;
+    const double *vnorm;
+    const double *vicov;
+    const uint32_t *cell_start;
+    // transform: float32 copy for the point transform, float64 rotation for the Jacobians
+    float r32[9], t32[3];
+    double R[9];
+    float md_f;        // gate, float32 compare (point targets)
+    double md_d;       // gate, float64 compare (voxel targets)
+    float bound2_f;    // search bound (squared), slightly above the gate
+    double bound2_d;
+    unsigned flags;
+    int nblocks;
+    double *partials;  // [nblocks][32]
+    // variant 1: correspondences through HBM
+    float *nn_dist;
+    uint32_t *nn_j;
+};
+
+__device__ __forceinline__ void xform(const LinArgs &a, float x, float y, float z, float &tx, float &ty, float &tz) {
+    // ((R00*x + R01*y) + R02*z) + t0, float32, no contraction: oracle orc_transform
+    tx = ((a.r32[0] * x + a.r32[1] * y) + a.r32[2] * z) + a.t32[0];
+    ty = ((a.r32[3] * x + a.r32[4] * y) + a.r32[5] * z) + a.t32[1];
+    tz = ((a.r32[6] * x + a.r32[7] * y) + a.r32[8] * z) + a.t32[2];
+}
+
+// ---- per-correspondence accumulation ------------------------------------------------------
+// acc layout for PLANE / VPLANE / NDT: 0..20 triu(H), 21..26 g, 27 e2, 28 count.
+// acc layout for ICP (closed form, icp.py:40-47): 0 count, 1..3 sum p, 4..9 second moments
+// (xx xy xz yy yz zz), 10..12 sum r, 13..15 sum p x v (v = R r or R^T r), 16 e2.
+
+__device__ __forceinline__ void acc_rank1(double *acc, const double J[6], double r) {
+    int p = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) { acc[p] = fma(J[i], J[j], acc[p]); ++p; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[21 + i] = fma(J[i], r, acc[21 + i]);
+    acc[27] = fma(r, r, acc[27]);
+    acc[28] += 1.0;
+}
+
+__device__ __forceinline__ void acc_plane(double *acc, const LinArgs &a, double x, double y, double z,
+                                          double n0, double n1, double n2, double d0, double d1, double d2) {
+    const double r = (n0 * d0 + n1 * d1) + n2 * d2;                          // plane_icp.py:49
+    const double ra = a.R[0] * n0 + a.R[3] * n1 + a.R[6] * n2;               // R^T n, plane_icp.py:51
+    const double rb = a.R[1] * n0 + a.R[4] * n1 + a.R[7] * n2;
+    const double rc = a.R[2] * n0 + a.R[5] * n1 + a.R[8] * n2;
+    const double J[6] = {n0, n1, n2, -z * rb + y * rc, z * ra - x * rc, -y * ra + x * rb};   // math_tools.py:22-31
+    acc_rank1(acc, J, r);
+}
+
+__device__ __forceinline__ void acc_icp(double *acc, const LinArgs &a, double x, double y, double z,
+                                        double r0, double r1, double r2) {
+    acc[0] += 1.0;
+    acc[1] += x; acc[2] += y; acc[3] += z;
+    acc[4] = fma(x, x, acc[4]); acc[5] = fma(x, y, acc[5]); acc[6] = fma(x, z, acc[6]);
+    acc[7] = fma(y, y, acc[7]); acc[8] = fma(y, z, acc[8]); acc[9] = fma(z, z, acc[9]);
+    acc[10] += r0; acc[11] += r1; acc[12] += r2;
+    double v0, v1, v2;
+    if (a.flags & PCR_FLAG_ICP_RR_QUIRK) {                                   // quirk Q1, icp.py:53-54
+        v0 = a.R[0] * r0 + a.R[1] * r1 + a.R[2] * r2;
+        v1 = a.R[3] * r0 + a.R[4] * r1 + a.R[5] * r2;
+        v2 = a.R[6] * r0 + a.R[7] * r1 + a.R[8] * r2;
+    } else {                                                                 // consistent J^T r, icp.py:81-87
+        v0 = a.R[0] * r0 + a.R[3] * r1 + a.R[6] * r2;
+        v1 = a.R[1] * r0 + a.R[4] * r1 + a.R[7] * r2;
+        v2 = a.R[2] * r0 + a.R[5] * r1 + a.R[8] * r2;
+    }
+    acc[13] += y * v2 - z * v1; acc[14] += z * v0 - x * v2; acc[15] += x * v1 - y * v0;
+    acc[16] += r0 * r0 + r1 * r1 + r2 * r2;
+}
+
+__device__ __forceinline__ void acc_ndt(double *acc, const LinArgs &a, double x, double y, double z,
+                                        const double *__restrict__ c6, double d0, double d1, double d2) {
+    // J = [I, -R skew(p)] (ndt.py:40); C symmetric inverse covariance
+    const double C[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+    double J[3][6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double ri0 = a.R[3 * i], ri1 = a.R[3 * i + 1], ri2 = a.R[3 * i + 2];
+        J[i][0] = i == 0; J[i][1] = i == 1; J[i][2] = i == 2;
+        // -(R S) with S = [[0,-z,y],[z,0,-x],[-y,x,0]]
+        J[i][3] = -(ri1 * z - ri2 * y);
+        J[i][4] = -(-ri0 * z + ri2 * x);
+        J[i][5] = -(ri0 * y - ri1 * x);
+    }
+    double CJ[3][6], Cd[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        Cd[i] = C[i][0] * d0 + C[i][1] * d1 + C[i][2] * d2;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) CJ[i][j] = C[i][0] * J[0][j] + C[i][1] * J[1][j] + C[i][2] * J[2][j];
+    }
+    int p = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) { acc[p] += J[0][i] * CJ[0][j] + J[1][i] * CJ[1][j] + J[2][i] * CJ[2][j]; ++p; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[21 + i] += J[0][i] * Cd[0] + J[1][i] * Cd[1] + J[2][i] * Cd[2];
+    acc[27] += d0 * Cd[0] + d1 * Cd[1] + d2 * Cd[2];
+    acc[28] += 1.0;
+}
+
+// gather the matched record at cell-sorted index j and accumulate
+template <int KIND>
+__device__ __forceinline__ void accumulate(double *acc, const LinArgs &a, uint32_t j,
+                                           float x, float y, float z, float tx, float ty, float tz) {
+    if (KIND == PCR_ICP) {
+        const PtF q = a.pts[j];
+        acc_icp(acc, a, x, y, z, (double)(tx - q.x), (double)(ty - q.y), (double)(tz - q.z));   // icp.py:39
+    } else if (KIND == PCR_PLANE) {
+        const PtF q = a.pts[j];
+        const float4 nn = a.normals[j];
+        acc_plane(acc, a, x, y, z, nn.x, nn.y, nn.z, (double)(tx - q.x), (double)(ty - q.y), (double)(tz - q.z));
+    } else if (KIND == PCR_VPLANE) {
+        const PtD q = a.means[j];
+        const double *nn = a.vnorm + 3 * (size_t)j;
+        acc_plane(acc, a, x, y, z, nn[0], nn[1], nn[2], (double)tx - q.x, (double)ty - q.y, (double)tz - q.z);
+    } else {
+        const PtD q = a.means[j];
+        acc_ndt(acc, a, x, y, z, a.vicov + 6 * (size_t)j, (double)tx - q.x, (double)ty - q.y, (double)tz - q.z);
+    }
+}
+
+// ---- block reduction of 32 float64 sums --------------------------------------------------
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, mask, 64);
+    hi = __shfl_xor(hi, mask, 64);
+    return __hiloint2double(hi, lo);
+}
+
+// After the call lane l holds the wave-wide sum of component (l >> 1) in acc[0].
+__device__ __forceinline__ void wave_fold32(double *acc, int lane) {
+#pragma unroll
+    for (int half = 16, mask = 32; half >= 1; half >>= 1, mask >>= 1) {
+        const bool upper = (lane & mask) != 0;
+#pragma unroll
+        for (int i = 0; i < half; ++i) {
+            const double send = upper ? acc[i] : acc[i + half];
+            const double keep = upper ? acc[i + half] : acc[i];
+            acc[i] = keep + shfl_xor_f64(send, mask);
+        }
+    }
+    acc[0] += shfl_xor_f64(acc[0], 1);
+}
+
+__device__ __forceinline__ void block_store_partials(double *acc, double *__restrict__ partials) {
+    __shared__ double wsum[4][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    wave_fold32(acc, lane);
+    if ((lane & 1) == 0) wsum[wave][lane >> 1] = acc[0];
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const double s = ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
+        partials[(size_t)blockIdx.x * 32 + threadIdx.x] = s;
+    }
+}
+
+__device__ __forceinline__ void block_chunk(const LinArgs &a, int64_t &lo, int64_t &hi) {
+    // XCD-aware contiguous chunks (nblocks is a multiple of 8)
+    const int per = a.nblocks >> 3;
+    const int v = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    const int64_t chunk = (((a.n + a.nblocks - 1) / a.nblocks) + 255) & ~(int64_t)255;
+    lo = (int64_t)v * chunk;
+    hi = lo + chunk < a.n ? lo + chunk : a.n;
+}
+
+// ---- variant 0: everything in one kernel ----------------------------------------------------
+template <int KIND>
+__global__ void __launch_bounds__(256) k_linearize(const LinArgs a) {
+    double acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+    int64_t lo, hi;
+    block_chunk(a, lo, hi);
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
+        float tx, ty, tz;
+        xform(a, x, y, z, tx, ty, tz);
+        uint32_t bj, bo;
+        bool ok;
+        if (KIND == PCR_ICP || KIND == PCR_PLANE) {
+            float best;
+            nn_search<float, PtF>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
+            ok = bj != PCR_NONE && __builtin_sqrtf(best) < a.md_f;                 // icp.py:34 strict gate
+        } else {
+            double best;
+            nn_search<double, PtD>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz, a.bound2_d, best, bj, bo);
+            ok = bj != PCR_NONE && __builtin_sqrt(best) < a.md_d;                 // voxelized_plane_icp.py:38
+        }
+        if (ok) accumulate<KIND>(acc, a, bj, x, y, z, tx, ty, tz);
+    }
+    block_store_partials(acc, a.partials);
+}
+
+// ---- variant 1: NN kernel (few registers, high occupancy) + streaming reduce kernel ---------
+template <int VOXEL>
+__global__ void __launch_bounds__(256) k_nn_scan(const LinArgs a) {
+    int64_t lo, hi;
+    block_chunk(a, lo, hi);
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
+        float tx, ty, tz;
+        xform(a, x, y, z, tx, ty, tz);
+        uint32_t bj, bo;
+        bool ok;
+        if (!VOXEL) {
+            float best;
+            nn_search<float, PtF>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
+            ok = bj != PCR_NONE && __builtin_sqrtf(best) < a.md_f;
+        } else {
+            double best;
+            nn_search<double, PtD>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz, a.bound2_d, best, bj, bo);
+            ok = bj != PCR_NONE && __builtin_sqrt(best) < a.md_d;
+        }
+        a.nn_j[i] = ok ? bj : PCR_NONE;
+    }
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256) k_reduce(const LinArgs a) {
+    double acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+    int64_t lo, hi;
+    block_chunk(a, lo, hi);
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const uint32_t j = a.nn_j[i];
+        if (j == PCR_NONE) continue;
+        const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
+        float tx, ty, tz;
+        xform(a, x, y, z, tx, ty, tz);
+        accumulate<KIND>(acc, a, j, x, y, z, tx, ty, tz);
+    }
+    block_store_partials(acc, a.partials);
+}
+
+// ---- fold the per-block partials in a fixed order and emit the 29-vector ---------------------
+struct FinArgs {
+    const double *partials;
+    int nblocks;
+    int kind;
+    double R[9];
+    double *out;   // 32 doubles
+};
+
+__global__ void __launch_bounds__(1024) k_finalize(const FinArgs f) {
+    __shared__ double part[32][33];
+    __shared__ double tot[32];
+    const int c = threadIdx.x & 31, r = threadIdx.x >> 5;     // 32 row-groups x 32 components
+    double s = 0.0;
+    for (int b = r; b < f.nblocks; b += 32) s += f.partials[(size_t)b * 32 + c];
+    part[r][c] = s;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double t = 0.0;
+        for (int k = 0; k < 32; ++k) t += part[k][threadIdx.x];
+        tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (f.kind != PCR_ICP) {
+            for (int i = 0; i < 29; ++i) f.out[i] = tot[i];
+        } else {
+            // H_ll = M I (icp.py:43); H_lr = -R skew(sum p) (icp.py:44); H_rr from the second
+            // moments (math_tools.py:44-58)
+            const double cnt = tot[0], sx = tot[1], sy = tot[2], sz = tot[3];
+            const double S[9] = {0, -sz, sy, sz, 0, -sx, -sy, sx, 0};
+            double H[6][6];
+            for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) H[i][j] = 0.0;
+            H[0][0] = H[1][1] = H[2][2] = cnt;
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) {
+                    double v = 0.0;
+                    for (int k = 0; k < 3; ++k) v += f.R[3 * i + k] * S[3 * k + j];
+                    H[i][3 + j] = -v;
+                }
+            const double xx = tot[4], xy = tot[5], xz = tot[6], yy = tot[7], yz = tot[8], zz = tot[9];
+            H[3][3] = yy + zz; H[3][4] = -xy; H[3][5] = -xz;
+            H[4][4] = xx + zz; H[4][5] = -yz; H[5][5] = xx + yy;
+            int p = 0;
+            for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) f.out[p++] = H[i][j];
+            for (int i = 0; i < 3; ++i) { f.out[21 + i] = tot[10 + i]; f.out[24 + i] = tot[13 + i]; }
+            f.out[27] = tot[16]; f.out[28] = cnt;
+        }
+        f.out[29] = 0; f.out[30] = 0; f.out[31] = 0;
+    }
+}
+
+// ---- fine seam: plain NN queries (no transform), original indices out -------------------------
+template <typename Real, typename PT>
+__global__ void __launch_bounds__(256) k_nn_query(Geom<Real> g, const PT *pts, const uint32_t *cs,
+                                                  const float *q, int64_t m, Real bound2, Real rmax,
+                                                  Real *dist, int64_t *idx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    Real best; uint32_t bj, bo;
+    nn_search<Real, PT>(g, pts, cs, (Real)q[3 * i], (Real)q[3 * i + 1], (Real)q[3 * i + 2], bound2, best, bj, bo);
+    Real d = RealTraits<Real>::sqrt_rn(best);
+    if (bj != PCR_NONE && rmax < RealTraits<Real>::inf() && !(d < rmax)) bj = PCR_NONE;
+    dist[i] = bj == PCR_NONE ? RealTraits<Real>::inf() : d;
+    idx[i] = bj == PCR_NONE ? (int64_t)-1 : (int64_t)bo;
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+pcr_status pcr_ensure_scratch(pcr_context *ctx, int64_t n_points) {
+    if (!ctx->d_partials) {
+        ctx->max_blocks = ctx->num_cu * 16;
+        HIP_TRY(hipMalloc(&ctx->d_partials, sizeof(double) * 32 * (size_t)ctx->max_blocks));
+        HIP_TRY(hipMalloc(&ctx->d_out, sizeof(double) * 32));
+        HIP_TRY(hipHostMalloc(&ctx->h_out, sizeof(double) * 32, hipHostMallocDefault));
+    }
+    if (ctx->variant == 1 && ctx->nn_cap < n_points) {
+        if (ctx->d_nn_j) HIP_TRY(hipFree(ctx->d_nn_j));
+        ctx->d_nn_j = nullptr;
+        HIP_TRY(hipMalloc(&ctx->d_nn_j, sizeof(uint32_t) * (size_t)n_points));
+        ctx->nn_cap = n_points;
+    }
+    return PCR_OK;
+}
+
+static int choose_blocks(const pcr_context *ctx, int64_t n) {
+    // enough 256-thread blocks to fill every CU several times over, never more than the work,
+    // always a multiple of 8 (one contiguous span of the scan per XCD)
+    int64_t want = (n + 255) / 256;
+    int64_t cap = (int64_t)ctx->num_cu * 8;
+    int64_t nb = want < cap ? want : cap;
+    nb = (nb + 7) & ~(int64_t)7;
+    if (nb < 8) nb = 8;
+    if (nb > ctx->max_blocks) nb = ctx->max_blocks;
+    return (int)nb;
+}
+
+pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double T[16], double max_dist,
+                             unsigned flags, double out[29]) {
+    pcr_context *ctx = t->ctx;
+    PCR_REQUIRE(s->ctx == ctx, "scan and target belong to different contexts");
+    PCR_REQUIRE(kind >= PCR_ICP && kind <= PCR_NDT, "unknown kind");
+    PCR_REQUIRE(max_dist > 0, "max_dist must be positive");
+    if ((kind == PCR_ICP || kind == PCR_PLANE) && t->is_voxel) {
+        pcr_set_error("kind %d needs a point target", kind);
+        return PCR_ERR_NO_TARGET;
+    }
+    if ((kind == PCR_VPLANE || kind == PCR_NDT) && !t->is_voxel) {
+        pcr_set_error("kind %d needs a voxel target", kind);
+        return PCR_ERR_NO_TARGET;
+    }
+    if (kind == PCR_PLANE && !t->normals) { pcr_set_error("PlaneICP target has no normals"); return PCR_ERR_NO_TARGET; }
+    if (kind == PCR_VPLANE && !t->vnorm) { pcr_set_error("VPlaneICP target has no voxel normals"); return PCR_ERR_NO_TARGET; }
+    if (kind == PCR_NDT && !t->vicov) { pcr_set_error("NDT target has no inverse covariances"); return PCR_ERR_NO_TARGET; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    PCR_TRY(pcr_ensure_scratch(ctx, s->n));
+
+    LinArgs a;
+    a.sx = s->x; a.sy = s->y; a.sz = s->z; a.n = s->n;
+    a.gf = t->gf; a.pts = t->pts; a.normals = t->normals;
+    a.gd = t->gd; a.means = t->means; a.vnorm = t->vnorm; a.vicov = t->vicov;
+    a.cell_start = t->cell_start;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) { a.R[3 * i + j] = T[4 * i + j]; a.r32[3 * i + j] = (float)T[4 * i + j]; }
+        a.t32[i] = (float)T[4 * i + 3];
+    }
+    a.md_f = (float)max_dist; a.md_d = max_dist;
+    const double bound = max_dist * (1.0 + 1e-6);
+    a.bound2_f = (float)(bound * bound); a.bound2_d = bound * bound;
+    a.flags = flags;
+    a.nblocks = choose_blocks(ctx, s->n);
+    a.partials = ctx->d_partials;
+    a.nn_dist = nullptr; a.nn_j = ctx->d_nn_j;
+
+    ProfEvent ev;
+    const dim3 grid(a.nblocks), block(256);
+    if (ctx->variant == 0) {
+        pcr_prof_begin(ctx, PCR_K_LINEARIZE, &ev);
+        switch (kind) {
+        case PCR_ICP: hipLaunchKernelGGL(k_linearize<PCR_ICP>, grid, block, 0, ctx->stream, a); break;
+        case PCR_PLANE: hipLaunchKernelGGL(k_linearize<PCR_PLANE>, grid, block, 0, ctx->stream, a); break;
+        case PCR_VPLANE: hipLaunchKernelGGL(k_linearize<PCR_VPLANE>, grid, block, 0, ctx->stream, a); break;
+        default: hipLaunchKernelGGL(k_linearize<PCR_NDT>, grid, block, 0, ctx->stream, a); break;
+        }
+        pcr_prof_end(ctx, &ev);
+    } else {
+        pcr_prof_begin(ctx, PCR_K_NN, &ev);
+        if (!t->is_voxel) hipLaunchKernelGGL(k_nn_scan<0>, grid, block, 0, ctx->stream, a);
+        else hipLaunchKernelGGL(k_nn_scan<1>, grid, block, 0, ctx->stream, a);
+        pcr_prof_end(ctx, &ev);
+        pcr_prof_begin(ctx, PCR_K_REDUCE, &ev);
+        switch (kind) {
+        case PCR_ICP: hipLaunchKernelGGL(k_reduce<PCR_ICP>, grid, block, 0, ctx->stream, a); break;
+        case PCR_PLANE: hipLaunchKernelGGL(k_reduce<PCR_PLANE>, grid, block, 0, ctx->stream, a); break;
+        case PCR_VPLANE: hipLaunchKernelGGL(k_reduce<PCR_VPLANE>, grid, block, 0, ctx->stream, a); break;
+        default: hipLaunchKernelGGL(k_reduce<PCR_NDT>, grid, block, 0, ctx->stream, a); break;
+        }
+        pcr_prof_end(ctx, &ev);
+    }
+    HIP_TRY(hipGetLastError());
+
+    FinArgs f;
+    f.partials = ctx->d_partials; f.nblocks = a.nblocks; f.kind = kind; f.out = ctx->d_out;
+    for (int i = 0; i < 9; ++i) f.R[i] = a.R[i];
+    pcr_prof_begin(ctx, PCR_K_FINALIZE, &ev);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, ctx->stream, f);
+    pcr_prof_end(ctx, &ev);
+    HIP_TRY(hipGetLastError());
+
+    if (ctx->comm) {
+        pcr_prof_begin(ctx, PCR_K_ALLREDUCE, &ev);
+        pcr_status cs = pcr_comm_allreduce29(ctx, ctx->d_out);
+        pcr_prof_end(ctx, &ev);
+        if (cs != PCR_OK) return cs;
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(double) * 29, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 29; ++i) out[i] = ctx->h_out[i];
+    return PCR_OK;
+}
+
+pcr_status pcr_run_nn(pcr_target *t, const float *d_q, int64_t m, double r_max, void *d_dist, int64_t *d_idx, int f64) {
+    pcr_context *ctx = t->ctx;
+    if (m == 0) return PCR_OK;
+    const dim3 grid((unsigned)((m + 255) / 256)), block(256);
+    const bool bounded = r_max > 0 && r_max < 1e300 * 1e300;
+    ProfEvent ev;
+    pcr_prof_begin(ctx, PCR_K_NN, &ev);
+    if (!f64) {
+        PCR_REQUIRE(!t->is_voxel, "pcr_nn_query needs a point target (use pcr_nn_query_f64 for voxels)");
+        const float inf = __builtin_inff();
+        const double b = r_max * (1.0 + 1e-6);
+        const float bound2 = bounded ? (float)(b * b) : inf;
+        hipLaunchKernelGGL((k_nn_query<float, PtF>), grid, block, 0, ctx->stream, t->gf, t->pts, t->cell_start, d_q, m,
+                           bound2, bounded ? (float)r_max : inf, (float *)d_dist, d_idx);
+    } else {
+        PCR_REQUIRE(t->is_voxel, "pcr_nn_query_f64 needs a voxel target");
+        const double inf = __builtin_inf();
+        const double b = r_max * (1.0 + 1e-6);
+        hipLaunchKernelGGL((k_nn_query<double, PtD>), grid, block, 0, ctx->stream, t->gd, t->means, t->cell_start, d_q, m,
+                           bounded ? b * b : inf, bounded ? r_max : inf, (double *)d_dist, d_idx);
+    }
+    pcr_prof_end(ctx, &ev);
+    HIP_TRY(hipGetLastError());
+    return PCR_OK;
+}

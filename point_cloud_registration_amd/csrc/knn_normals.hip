@@ -1,0 +1,224 @@
+// Exact k nearest neighbours over the target's cell grid and k-NN PCA normals.
+//
+//   pcr_knn_query               KDTree(data).query(points, k) of the reference (kdtree.py:18-65)
+//   pcr_target_estimate_normals estimate_norm_with_tree (estimate_normals.py:27-87): k-NN of every
+//                               target point, covariance of the neighbours, eigenvector of the
+//                               smallest eigenvalue
+//
+// One lane = one query.  The running top-k list (squared distance, cell-sorted index) lives in
+// LDS, laid out [slot][lane] so a wave's accesses to one slot hit 64 different banks.  The search
+// is the ring expansion of nn_device.h with the k-th best distance as the pruning bound; ties are
+// ordered by (distance, original index), the oracle's rule (orc_knn_brute_f32).
+#include "eigen3.h"
+#include "nn_device.h"
+
+#define KNN_BLOCK 64
+#define KNN_MAX_K 64
+
+struct KnnList {
+    float *d;        // [k][KNN_BLOCK] squared distances, ascending
+    uint32_t *j;     // [k][KNN_BLOCK] cell-sorted indices
+    uint32_t *o;     // [k][KNN_BLOCK] original indices
+    int k, cnt, lane;
+    __device__ __forceinline__ float &D(int s) { return d[s * KNN_BLOCK + lane]; }
+    __device__ __forceinline__ uint32_t &J(int s) { return j[s * KNN_BLOCK + lane]; }
+    __device__ __forceinline__ uint32_t &O(int s) { return o[s * KNN_BLOCK + lane]; }
+};
+
+__device__ __forceinline__ void knn_offer(KnnList &L, float dist2, uint32_t jj, uint32_t oo, float &kth, uint32_t &kth_o) {
+    if (L.cnt == L.k && !(dist2 < kth || (dist2 == kth && oo < kth_o))) return;
+    int p = L.cnt < L.k ? L.cnt : L.k - 1;
+    while (p > 0) {
+        const float dp = L.D(p - 1);
+        const uint32_t op = L.O(p - 1);
+        if (!(dp > dist2 || (dp == dist2 && op > oo))) break;
+        L.D(p) = dp; L.J(p) = L.J(p - 1); L.O(p) = op;
+        --p;
+    }
+    L.D(p) = dist2; L.J(p) = jj; L.O(p) = oo;
+    if (L.cnt < L.k) ++L.cnt;
+    if (L.cnt == L.k) { kth = L.D(L.k - 1); kth_o = L.O(L.k - 1); }
+}
+
+__device__ __forceinline__ void knn_scan_range(KnnList &L, const PtF *__restrict__ pts, uint32_t s, uint32_t e,
+                                               float qx, float qy, float qz, float &kth, uint32_t &kth_o) {
+    for (uint32_t j = s; j < e; ++j) {
+        const PtF p = pts[j];
+        const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        knn_offer(L, d, j, pt_orig(p), kth, kth_o);
+    }
+}
+
+__device__ __forceinline__ void knn_search(const Geom<float> &g, const PtF *__restrict__ pts,
+                                           const uint32_t *__restrict__ cs, float qx, float qy, float qz, KnnList &L) {
+    const float INF = __int_as_float(0x7f800000);
+    float kth = INF;
+    uint32_t kth_o = PCR_NONE;
+    L.cnt = 0;
+    const float lim = 1.0e9f;
+    float rx = (qx - g.ox) * g.inv_h, ry = (qy - g.oy) * g.inv_h, rz = (qz - g.oz) * g.inv_h;
+    rx = fminf(fmaxf(rx, -lim), lim); ry = fminf(fmaxf(ry, -lim), lim); rz = fminf(fmaxf(rz, -lim), lim);
+    const int cx = (int)floorf(rx), cy = (int)floorf(ry), cz = (int)floorf(rz);
+    const float fx = (qx - g.ox) - (float)cx * g.h, fy = (qy - g.oy) - (float)cy * g.h, fz = (qz - g.oz) - (float)cz * g.h;
+    const float fmin_ = fminf(fminf(fminf(fx, g.h - fx), fminf(fy, g.h - fy)), fminf(fz, g.h - fz));
+    const int k0 = max(max(max(-cx, cx - (g.nx - 1)), max(-cy, cy - (g.ny - 1))), max(max(-cz, cz - (g.nz - 1)), 0));
+    const int kmax = max(max(max(cx, g.nx - 1 - cx), max(cy, g.ny - 1 - cy)), max(cz, g.nz - 1 - cz));
+    for (int k = k0; k <= kmax; ++k) {
+        if (k >= 1) {
+            const float lb = (float)(k - 1) * g.h + fmin_ - g.slack;
+            if (lb > 0.f && lb * lb > kth) break;
+        }
+        const int zlo = max(cz - k, 0), zhi = min(cz + k, g.nz - 1);
+        const int ylo = max(cy - k, 0), yhi = min(cy + k, g.ny - 1);
+        for (int z = zlo; z <= zhi; ++z) {
+            const int dzc = z - cz;
+            float dzm = dzc == 0 ? 0.f : (dzc > 0 ? (float)dzc * g.h - fz : (float)(-dzc - 1) * g.h + fz);
+            dzm = fmaxf(dzm - g.slack, 0.f);
+            const float dz2 = dzm * dzm;
+            if (dz2 > kth) continue;
+            const bool zshell = (dzc == k) || (dzc == -k);
+            for (int y = ylo; y <= yhi; ++y) {
+                const int dyc = y - cy;
+                float dym = dyc == 0 ? 0.f : (dyc > 0 ? (float)dyc * g.h - fy : (float)(-dyc - 1) * g.h + fy);
+                dym = fmaxf(dym - g.slack, 0.f);
+                const float dyz2 = dz2 + dym * dym;
+                if (dyz2 > kth) continue;
+                const size_t row = ((size_t)z * (size_t)g.ny + (size_t)y) * (size_t)g.nx;
+                if (zshell || dyc == k || dyc == -k) {
+                    int xl = max(cx - k, 0), xh = min(cx + k, g.nx - 1);
+                    if (kth < INF) {
+                        const float xr = __builtin_sqrtf(kth - dyz2) + g.slack;
+                        const float a = (qx - xr - g.ox) * g.inv_h, b = (qx + xr - g.ox) * g.inv_h;
+                        if (a > (float)xl) xl = (int)floorf(fminf(a, lim));
+                        if (b < (float)xh) xh = (int)floorf(fmaxf(b, -lim));
+                    }
+                    if (xl <= xh) knn_scan_range(L, pts, cs[row + xl], cs[row + xh + 1], qx, qy, qz, kth, kth_o);
+                } else {
+                    const int xa = cx - k, xb = cx + k;
+                    if (xa >= 0 && xa < g.nx) {
+                        const float dxm = fmaxf((float)(k - 1) * g.h + fx - g.slack, 0.f);
+                        if (dyz2 + dxm * dxm <= kth) knn_scan_range(L, pts, cs[row + xa], cs[row + xa + 1], qx, qy, qz, kth, kth_o);
+                    }
+                    if (xb >= 0 && xb < g.nx) {
+                        const float dxm = fmaxf((float)k * g.h - fx - g.slack, 0.f);
+                        if (dyz2 + dxm * dxm <= kth) knn_scan_range(L, pts, cs[row + xb], cs[row + xb + 1], qx, qy, qz, kth, kth_o);
+                    }
+                }
+            }
+        }
+    }
+}
+
+extern __shared__ __attribute__((aligned(16))) char knn_smem[];
+
+__device__ __forceinline__ KnnList knn_list(int k) {
+    KnnList L;
+    L.k = k; L.cnt = 0; L.lane = threadIdx.x;
+    L.d = (float *)knn_smem;
+    L.j = (uint32_t *)(knn_smem + sizeof(float) * k * KNN_BLOCK);
+    L.o = (uint32_t *)(knn_smem + 2 * sizeof(float) * k * KNN_BLOCK);
+    return L;
+}
+
+__global__ void __launch_bounds__(KNN_BLOCK) k_knn_query(Geom<float> g, const PtF *pts, const uint32_t *cs, int64_t n_target,
+                                                         const float *q, int64_t m, int k, float *dist, int64_t *idx) {
+    const int64_t i = (int64_t)blockIdx.x * KNN_BLOCK + threadIdx.x;
+    if (i >= m) return;
+    KnnList L = knn_list(k);
+    knn_search(g, pts, cs, q[3 * i], q[3 * i + 1], q[3 * i + 2], L);
+    for (int s = 0; s < k; ++s) {
+        const bool have = s < L.cnt;
+        dist[i * k + s] = have ? __builtin_sqrtf(L.D(s)) : __int_as_float(0x7f800000);
+        idx[i * k + s] = have ? (int64_t)L.O(s) : n_target;
+    }
+}
+
+// normals of the target's own points, processed (and written) in cell-sorted order
+__global__ void __launch_bounds__(KNN_BLOCK) k_knn_normals(Geom<float> g, const PtF *pts, const uint32_t *cs, int64_t n,
+                                                           int k, int compat, float4 *normals) {
+    const int64_t i = (int64_t)blockIdx.x * KNN_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    KnnList L = knn_list(k);
+    const PtF me = pts[i];
+    knn_search(g, pts, cs, me.x, me.y, me.z, L);
+    double c[6];
+    if (compat) {
+        // estimate_normals.py:56-72: float32 running sums over the neighbours (nearest first),
+        // cov = E[pp^T] - mu mu^T in float32
+        float sx = 0, sy = 0, sz = 0, xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+        for (int s = 0; s < L.cnt; ++s) {
+            const PtF p = pts[L.J(s)];
+            sx += p.x; sy += p.y; sz += p.z;
+            xx += p.x * p.x; xy += p.x * p.y; xz += p.x * p.z; yy += p.y * p.y; yz += p.y * p.z; zz += p.z * p.z;
+        }
+        const float kf = (float)k;
+        const float mx = sx / kf, my = sy / kf, mz = sz / kf;
+        c[0] = xx / kf - mx * mx; c[1] = xy / kf - mx * my; c[2] = xz / kf - mx * mz;
+        c[3] = yy / kf - my * my; c[4] = yz / kf - my * mz; c[5] = zz / kf - mz * mz;
+    } else {
+        double mx = 0, my = 0, mz = 0;
+        for (int s = 0; s < L.cnt; ++s) { const PtF p = pts[L.J(s)]; mx += p.x; my += p.y; mz += p.z; }
+        const double kd = (double)(L.cnt > 0 ? L.cnt : 1);
+        mx /= kd; my /= kd; mz /= kd;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) c[a] = 0;
+        for (int s = 0; s < L.cnt; ++s) {
+            const PtF p = pts[L.J(s)];
+            const double dx = p.x - mx, dy = p.y - my, dz = p.z - mz;
+            c[0] += dx * dx; c[1] += dx * dy; c[2] += dx * dz; c[3] += dy * dy; c[4] += dy * dz; c[5] += dz * dz;
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) c[a] /= kd;
+    }
+    double nv[3];
+    smallest_eigvec3(c, nv);
+    normals[i] = make_float4((float)nv[0], (float)nv[1], (float)nv[2], 0.f);
+}
+
+static pcr_status check_k(int k) {
+    if (k < 1 || k > KNN_MAX_K) { pcr_set_error("k must be in [1, %d]", KNN_MAX_K); return PCR_ERR_INVALID; }
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_knn_query(pcr_target *t, const float *q, int64_t m, int k, float *dist, int64_t *idx) {
+    PCR_REQUIRE(t && (q || m == 0) && (dist || m == 0) && (idx || m == 0), "NULL argument");
+    PCR_REQUIRE(!t->is_voxel, "k-NN needs a point target");
+    PCR_TRY(check_k(k));
+    pcr_context *ctx = t->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (m == 0) return PCR_OK;
+    float *d_q = nullptr, *d_dist = nullptr;
+    int64_t *d_idx = nullptr;
+    HIP_TRY(hipMalloc(&d_q, 12 * (size_t)m));
+    HIP_TRY(hipMalloc(&d_dist, 4 * (size_t)m * k));
+    HIP_TRY(hipMalloc(&d_idx, 8 * (size_t)m * k));
+    HIP_TRY(hipMemcpyAsync(d_q, q, 12 * (size_t)m, hipMemcpyHostToDevice, ctx->stream));
+    const size_t smem = 3 * sizeof(float) * (size_t)k * KNN_BLOCK;
+    hipLaunchKernelGGL(k_knn_query, dim3((unsigned)((m + KNN_BLOCK - 1) / KNN_BLOCK)), dim3(KNN_BLOCK), smem, ctx->stream,
+                       t->gf, t->pts, t->cell_start, t->n, d_q, m, k, d_dist, d_idx);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(dist, d_dist, 4 * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(idx, d_idx, 8 * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d_q)); HIP_TRY(hipFree(d_dist)); HIP_TRY(hipFree(d_idx));
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_target_estimate_normals(pcr_target *t, int k, int compat, float *normals_out) {
+    PCR_REQUIRE(t, "NULL argument");
+    PCR_REQUIRE(!t->is_voxel, "normals belong to point targets");
+    PCR_TRY(check_k(k));
+    pcr_context *ctx = t->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!t->normals) HIP_TRY(hipMalloc(&t->normals, sizeof(float4) * (size_t)(t->n ? t->n : 1)));
+    if (t->n > 0) {
+        const size_t smem = 3 * sizeof(float) * (size_t)k * KNN_BLOCK;
+        hipLaunchKernelGGL(k_knn_normals, dim3((unsigned)((t->n + KNN_BLOCK - 1) / KNN_BLOCK)), dim3(KNN_BLOCK), smem,
+                           ctx->stream, t->gf, t->pts, t->cell_start, t->n, k, compat, t->normals);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    if (normals_out) return pcr_target_get_normals(t, normals_out);
+    return PCR_OK;
+}

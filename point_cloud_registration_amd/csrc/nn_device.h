@@ -1,0 +1,126 @@
+// Exact bounded nearest-neighbour search over a dense cell grid (device functions).
+//
+// Replaces KDTree.query (reference kdtree.py:18-21 -> pykdtree) and VoxelGrid.query's
+// KD-tree over centroids (voxel.py:165,171-179).  One lane = one query.  Points are stored
+// cell-sorted (cell id = (z*ny + y)*nx + x) as 16-byte (float4) or 32-byte (double4) records
+// with the original index bit-cast into w, so a ROW of cells x0..x1 at fixed (y, z) is one
+// contiguous range [cell_start[row+x0], cell_start[row+x1+1]) of HBM: a ring of the search is
+// a handful of contiguous row segments, not 26 scattered cells.
+//
+// Search: Chebyshev rings k = 0, 1, ... around the query's cell.  After ring k-1 every
+// unvisited point is at least (k-1)*h + (distance to the nearest face of the query's cell)
+// away, which certifies the current best and ends the search.  Inside a ring, rows are
+// skipped by their (y, z) slab distance and the x extent is clipped to the remaining budget
+// sqrt(best - dyz^2).  All bounds are loosened by geom.slack so that float rounding in the
+// cell assignment can never prune the true nearest neighbour.  Ties in distance are broken by
+// the smaller original index (the oracle's rule), which makes the result independent of the
+// storage order.
+//
+// Arithmetic: d2 = (dx*dx + dy*dy) + dz*dz in Real (float for point targets, double for
+// centroids), no FMA contraction (the TU is compiled with -ffp-contract=off) -- identical to
+// oracle/pcr_oracle.c d2f / d2d, so both pick the same neighbour bit for bit.
+#pragma once
+
+#include "pcr_internal.h"
+
+#define PCR_NONE 0xffffffffu
+
+__device__ __forceinline__ uint32_t pt_orig(const float4 &p) { return __float_as_uint(p.w); }
+__device__ __forceinline__ uint32_t pt_orig(const double4 &p) { return (uint32_t)__double_as_longlong(p.w); }
+
+template <typename Real> struct RealTraits;
+template <> struct RealTraits<float> {
+    __device__ static __forceinline__ float inf() { return __int_as_float(0x7f800000); }
+    __device__ static __forceinline__ float sqrt_rn(float x) { return __builtin_sqrtf(x); }   // correctly rounded (hipcc default); __fsqrt_rn maps to the NATIVE sqrt
+    __device__ static __forceinline__ float floor_(float x) { return floorf(x); }
+};
+template <> struct RealTraits<double> {
+    __device__ static __forceinline__ double inf() { return __longlong_as_double(0x7ff0000000000000LL); }
+    __device__ static __forceinline__ double sqrt_rn(double x) { return __builtin_sqrt(x); }
+    __device__ static __forceinline__ double floor_(double x) { return floor(x); }
+};
+
+template <typename Real, typename PT>
+__device__ __forceinline__ void nn_scan_range(const PT *__restrict__ pts, uint32_t s, uint32_t e,
+                                              Real qx, Real qy, Real qz,
+                                              Real &best, uint32_t &bj, uint32_t &borig) {
+    for (uint32_t j = s; j < e; ++j) {
+        const PT p = pts[j];
+        const Real dx = qx - (Real)p.x, dy = qy - (Real)p.y, dz = qz - (Real)p.z;
+        const Real d = (dx * dx + dy * dy) + dz * dz;
+        const uint32_t o = pt_orig(p);
+        if (d < best || (d == best && o < borig)) { best = d; bj = j; borig = o; }
+    }
+}
+
+// On return: bj = cell-sorted index of the nearest point (PCR_NONE if nothing closer than
+// sqrt(bound2)), best = its squared distance, borig = its original index.
+template <typename Real, typename PT>
+__device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restrict__ pts,
+                                          const uint32_t *__restrict__ cs,
+                                          Real qx, Real qy, Real qz, Real bound2,
+                                          Real &best, uint32_t &bj, uint32_t &borig) {
+    typedef RealTraits<Real> RT;
+    best = bound2; bj = PCR_NONE; borig = PCR_NONE;
+    const Real lim = (Real)1.0e9;
+    Real rx = (qx - g.ox) * g.inv_h, ry = (qy - g.oy) * g.inv_h, rz = (qz - g.oz) * g.inv_h;
+    rx = fmin(fmax(rx, -lim), lim); ry = fmin(fmax(ry, -lim), lim); rz = fmin(fmax(rz, -lim), lim);
+    const int cx = (int)RT::floor_(rx), cy = (int)RT::floor_(ry), cz = (int)RT::floor_(rz);
+    // offsets of the query inside its own cell
+    const Real fx = (qx - g.ox) - (Real)cx * g.h, fy = (qy - g.oy) - (Real)cy * g.h, fz = (qz - g.oz) - (Real)cz * g.h;
+    const Real fmin_ = fmin(fmin(fmin(fx, g.h - fx), fmin(fy, g.h - fy)), fmin(fz, g.h - fz));
+    // rings that can touch the grid box
+    const int k0 = max(max(max(-cx, cx - (g.nx - 1)), max(-cy, cy - (g.ny - 1))), max(max(-cz, cz - (g.nz - 1)), 0));
+    int kmax = max(max(max(cx, g.nx - 1 - cx), max(cy, g.ny - 1 - cy)), max(cz, g.nz - 1 - cz));
+    if (bound2 < RT::inf()) {
+        const Real kr = RT::sqrt_rn(bound2) * g.inv_h + (Real)2;
+        if (kr < (Real)kmax) kmax = (int)kr;
+    }
+    for (int k = k0; k <= kmax; ++k) {
+        if (k >= 1) {
+            const Real lb = (Real)(k - 1) * g.h + fmin_ - g.slack;
+            if (lb > (Real)0 && lb * lb > best) break;
+        }
+        const int zlo = max(cz - k, 0), zhi = min(cz + k, g.nz - 1);
+        const int ylo = max(cy - k, 0), yhi = min(cy + k, g.ny - 1);
+        for (int z = zlo; z <= zhi; ++z) {
+            const int dzc = z - cz;
+            Real dzm = dzc == 0 ? (Real)0 : (dzc > 0 ? (Real)dzc * g.h - fz : (Real)(-dzc - 1) * g.h + fz);
+            dzm = fmax(dzm - g.slack, (Real)0);
+            const Real dz2 = dzm * dzm;
+            if (dz2 > best) continue;
+            const bool zshell = (dzc == k) || (dzc == -k);
+            for (int y = ylo; y <= yhi; ++y) {
+                const int dyc = y - cy;
+                Real dym = dyc == 0 ? (Real)0 : (dyc > 0 ? (Real)dyc * g.h - fy : (Real)(-dyc - 1) * g.h + fy);
+                dym = fmax(dym - g.slack, (Real)0);
+                const Real dyz2 = dz2 + dym * dym;
+                if (dyz2 > best) continue;
+                const size_t row = ((size_t)z * (size_t)g.ny + (size_t)y) * (size_t)g.nx;
+                if (zshell || dyc == k || dyc == -k) {
+                    int xl = max(cx - k, 0), xh = min(cx + k, g.nx - 1);
+                    if (best < RT::inf()) {                 // clip the row to the remaining budget
+                        const Real xr = RT::sqrt_rn(best - dyz2) + g.slack;
+                        const Real a = (qx - xr - g.ox) * g.inv_h, b = (qx + xr - g.ox) * g.inv_h;
+                        if (a > (Real)xl) xl = (int)RT::floor_(fmin(a, lim));
+                        if (b < (Real)xh) xh = (int)RT::floor_(fmax(b, -lim));
+                    }
+                    if (xl <= xh)
+                        nn_scan_range<Real, PT>(pts, cs[row + xl], cs[row + xh + 1], qx, qy, qz, best, bj, borig);
+                } else {                                    // interior row of the ring: its two end cells
+                    const int xa = cx - k, xb = cx + k;
+                    if (xa >= 0 && xa < g.nx) {
+                        const Real dxm = fmax((Real)(k - 1) * g.h + fx - g.slack, (Real)0);
+                        if (dyz2 + dxm * dxm <= best)
+                            nn_scan_range<Real, PT>(pts, cs[row + xa], cs[row + xa + 1], qx, qy, qz, best, bj, borig);
+                    }
+                    if (xb >= 0 && xb < g.nx) {
+                        const Real dxm = fmax((Real)k * g.h - fx - g.slack, (Real)0);
+                        if (dyz2 + dxm * dxm <= best)
+                            nn_scan_range<Real, PT>(pts, cs[row + xb], cs[row + xb + 1], qx, qy, qz, best, bj, borig);
+                    }
+                }
+            }
+        }
+    }
+}

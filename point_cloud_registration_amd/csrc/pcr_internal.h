@@ -1,0 +1,125 @@
+// Internal declarations shared by the translation units of libpcr_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <vector>
+
+#include "pcr.h"
+
+void pcr_set_error(const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            pcr_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return PCR_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+
+#define PCR_TRY(expr)                      \
+    do {                                   \
+        pcr_status s_ = (expr);            \
+        if (s_ != PCR_OK) return s_;       \
+    } while (0)
+
+#define PCR_REQUIRE(cond, msg)                      \
+    do {                                            \
+        if (!(cond)) {                              \
+            pcr_set_error("invalid argument: %s", msg); \
+            return PCR_ERR_INVALID;                 \
+        }                                           \
+    } while (0)
+
+// Dense cell grid geometry.  Real = float for point targets, double for voxel centroids.
+template <typename Real>
+struct Geom {
+    Real ox, oy, oz;   // min corner
+    Real h, inv_h;     // cell edge and its reciprocal
+    Real slack;        // conservative margin on every pruning bound (rounding of cell assignment)
+    int nx, ny, nz;
+};
+
+// points of a grid, cell-sorted: xyz + original index bit-cast into w
+typedef float4 PtF;
+typedef double4 PtD;
+
+struct ProfEvent {
+    int kernel;
+    hipEvent_t start, stop;
+};
+
+struct pcr_context {
+    int device = 0;
+    int num_cu = 256;
+    hipStream_t stream = nullptr;
+    // reduction scratch
+    double *d_partials = nullptr;   // [max_blocks][32]
+    int max_blocks = 0;
+    double *d_out = nullptr;        // 32 doubles (29 used)
+    double *h_out = nullptr;        // pinned
+    // variant-1 scratch (NN results in HBM)
+    float *d_nn_dist = nullptr;
+    uint32_t *d_nn_j = nullptr;
+    int64_t nn_cap = 0;
+    int variant = 0;
+    // profiling
+    bool prof_on = false;
+    std::vector<ProfEvent> prof_events;
+    std::vector<ProfEvent> prof_free;
+    int64_t prof_launches[PCR_K_COUNT] = {0};
+    double prof_ms[PCR_K_COUNT] = {0};
+    // RCCL
+    void *comm = nullptr;
+    int nranks = 1, rank = 0;
+};
+
+struct pcr_target {
+    pcr_context *ctx = nullptr;
+    int is_voxel = 0;
+    int64_t n = 0;           // points or kept voxels
+    int64_t occupied = 0;    // occupied cells of the NN grid
+    uint32_t *cell_start = nullptr;
+    // point targets
+    Geom<float> gf;
+    PtF *pts = nullptr;        // cell-sorted
+    float4 *normals = nullptr; // cell-sorted, w unused
+    // voxel targets
+    Geom<double> gd;
+    PtD *means = nullptr;      // cell-sorted
+    double *vnorm = nullptr;   // [n][3] cell-sorted
+    double *vicov = nullptr;   // [n][6] cell-sorted (xx xy xz yy yz zz)
+    // voxel statistics in key order (device), for read-back
+    double *st_mean = nullptr, *st_cov = nullptr, *st_norm = nullptr, *st_icov = nullptr;
+    int64_t *st_counts = nullptr, *st_keys = nullptr;
+    double voxel_size = 0;
+};
+
+struct pcr_scan {
+    pcr_context *ctx = nullptr;
+    int64_t n = 0;
+    float *x = nullptr, *y = nullptr, *z = nullptr;   // SoA, Morton-sorted unless PCR_FLAG_NO_SCAN_SORT
+};
+
+// ---- index_build.hip
+pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n, float cell_hint, pcr_target *t);
+pcr_status pcr_build_centroid_grid(pcr_context *ctx, const double *d_mean, int64_t n, double cell, pcr_target *t);
+pcr_status pcr_sort_scan(pcr_context *ctx, const float *d_xyz, int64_t n, unsigned flags, pcr_scan *s);
+pcr_status pcr_permute_rows_f32(pcr_context *ctx, const float *d_in, int64_t n, int width, const PtF *pts, float4 *out);
+pcr_status pcr_permute_rows_f64(pcr_context *ctx, const double *d_in, int64_t n, int in_stride, const int *cols,
+                                int ncols, const PtD *means, double *out);
+
+// ---- kernels.hip
+pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double T[16], double max_dist,
+                             unsigned flags, double out[29]);
+pcr_status pcr_run_nn(pcr_target *t, const float *d_q, int64_t m, double r_max, void *d_dist, int64_t *d_idx, int f64);
+pcr_status pcr_ensure_scratch(pcr_context *ctx, int64_t n_points);
+
+// ---- profiling helpers (api.cpp)
+void pcr_prof_begin(pcr_context *ctx, int kernel, ProfEvent *ev);
+void pcr_prof_end(pcr_context *ctx, ProfEvent *ev);
+
+// ---- comm.cpp
+pcr_status pcr_comm_allreduce29(pcr_context *ctx, double *d_buf);

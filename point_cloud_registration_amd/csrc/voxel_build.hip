@@ -1,0 +1,179 @@
+// GPU build of a voxel target = VoxelGrid.set_points + calc_icov of the reference
+// (voxel.py:104-165, 69-102), behind pcr_target_voxels_create.
+//
+//   keys      k_voxel_keys     integer hash of floor(p / voxel_size), evaluated in the dtype of the
+//                              cloud (voxel.py:12-21; bit-exact: integer work)
+//   grouping  rocPRIM radix sort of (key, point index) + run-length encode: voxels come out in
+//             ascending key order (np.unique) and, the sort being stable, every voxel's points in
+//             ascending point index (np.bincount's accumulation order)
+//   stats     k_voxel_stats    one lane per kept voxel: float64 mean, two-pass sample covariance
+//                              / max(n-1, 1), smallest-eigenvector normal, closed-form inverse
+//   index     pcr_voxel_target_finish: dense grid over the kept centroids (float64 search)
+#include <hipcub/hipcub.hpp>
+
+#include "eigen3.h"
+#include "pcr_internal.h"
+
+pcr_status pcr_voxel_target_finish(pcr_context *ctx, pcr_target *t, double voxel_size);   // api.hip
+
+__device__ __forceinline__ long long pymod(long long a, long long m) {
+    const long long r = a % m;
+    return r < 0 ? r + m : r;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_voxel_keys(const T *__restrict__ xyz, int64_t n, T voxel_size,
+                                                    long long *keys, uint32_t *idx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long P = 116101LL, M = 10000000000LL;
+    // floor(points / voxel_size).astype(int64) in the array's own precision (voxel.py:16)
+    const long long x = (long long)floor(xyz[3 * i] / voxel_size);
+    const long long y = (long long)floor(xyz[3 * i + 1] / voxel_size);
+    const long long z = (long long)floor(xyz[3 * i + 2] / voxel_size);
+    keys[i] = pymod((pymod(z * P, M) + y) * P, M) + x;                            // voxel.py:20
+    idx[i] = (uint32_t)i;
+}
+
+__global__ void __launch_bounds__(256) k_keep_flags(const uint32_t *__restrict__ counts, int64_t nu, int min_points,
+                                                    uint32_t *flags) {
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v < nu) flags[v] = counts[v] >= (uint32_t)min_points ? 1u : 0u;
+    if (v == nu) flags[v] = 0u;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(128) k_voxel_stats(const T *__restrict__ xyz, const uint32_t *__restrict__ order,
+                                                     const long long *__restrict__ ukeys,
+                                                     const uint32_t *__restrict__ counts,
+                                                     const uint32_t *__restrict__ seg_start,
+                                                     const uint32_t *__restrict__ keep_pos, int64_t nu, int min_points,
+                                                     double *mean, double *cov, double *norm, double *icov,
+                                                     int64_t *out_counts, int64_t *out_keys) {
+    const int64_t v = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    if (v >= nu) return;
+    const uint32_t cnt = counts[v];
+    if (cnt < (uint32_t)min_points) return;                                        // voxel.py:151
+    const uint32_t s = seg_start[v], o = keep_pos[v];
+    double sx = 0, sy = 0, sz = 0;
+    for (uint32_t t = 0; t < cnt; ++t) {                                           // bincount order
+        const size_t i = order[s + t];
+        sx += (double)xyz[3 * i]; sy += (double)xyz[3 * i + 1]; sz += (double)xyz[3 * i + 2];
+    }
+    const double mx = sx / (double)cnt, my = sy / (double)cnt, mz = sz / (double)cnt;     // voxel.py:118-121
+    double c[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t t = 0; t < cnt; ++t) {
+        const size_t i = order[s + t];
+        const double dx = (double)xyz[3 * i] - mx, dy = (double)xyz[3 * i + 1] - my, dz = (double)xyz[3 * i + 2] - mz;
+        c[0] += dx * dx; c[1] += dx * dy; c[2] += dx * dz; c[3] += dy * dy; c[4] += dy * dz; c[5] += dz * dz;
+    }
+    const double den = (double)(cnt > 2 ? cnt - 1 : 1);                            // max(n-1, 1), voxel.py:136
+#pragma unroll
+    for (int a = 0; a < 6; ++a) c[a] /= den;
+    mean[3 * (size_t)o] = mx; mean[3 * (size_t)o + 1] = my; mean[3 * (size_t)o + 2] = mz;
+    double m9[9] = {c[0], c[1], c[2], c[1], c[3], c[4], c[2], c[4], c[5]};
+#pragma unroll
+    for (int a = 0; a < 9; ++a) cov[9 * (size_t)o + a] = m9[a];
+    double nv[3];
+    smallest_eigvec3(c, nv);                                                       // voxel.py:157-158
+    norm[3 * (size_t)o] = nv[0]; norm[3 * (size_t)o + 1] = nv[1]; norm[3 * (size_t)o + 2] = nv[2];
+    double ic[9];
+    icov_closed_form(m9, ic);                                                      // voxel.py:69-102
+#pragma unroll
+    for (int a = 0; a < 9; ++a) icov[9 * (size_t)o + a] = ic[a];
+    out_counts[o] = (int64_t)cnt;
+    out_keys[o] = ukeys[v];
+}
+
+template <typename T>
+static pcr_status voxel_build(pcr_context *ctx, const T *d_xyz, int64_t n, double voxel_size, int min_points,
+                              pcr_target *t) {
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    long long *k1 = nullptr, *k2 = nullptr, *ukeys = nullptr;
+    uint32_t *i1 = nullptr, *i2 = nullptr, *counts = nullptr, *seg = nullptr, *flags = nullptr;
+    int *d_runs = nullptr;
+    void *tmp = nullptr;
+    pcr_status st = PCR_OK;
+    int64_t nu = 0, nk = 0;
+#define VB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { pcr_set_error("%s failed: %s", #expr, hipGetErrorString(e_)); st = PCR_ERR_HIP; goto done; } } while (0)
+    VB_TRY(hipMalloc(&k1, 8 * nn)); VB_TRY(hipMalloc(&k2, 8 * nn)); VB_TRY(hipMalloc(&ukeys, 8 * nn));
+    VB_TRY(hipMalloc(&i1, 4 * nn)); VB_TRY(hipMalloc(&i2, 4 * nn));
+    VB_TRY(hipMalloc(&counts, 4 * (nn + 1))); VB_TRY(hipMalloc(&seg, 4 * (nn + 1))); VB_TRY(hipMalloc(&flags, 4 * (nn + 1)));
+    VB_TRY(hipMalloc(&d_runs, sizeof(int)));
+    if (n > 0) {
+        hipLaunchKernelGGL(k_voxel_keys<T>, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, (T)voxel_size, k1, i1);
+        size_t tb = 0;
+        VB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k1, k2, i1, i2, (int)n, 0, 64, ctx->stream));
+        VB_TRY(hipMalloc(&tmp, tb ? tb : 16));
+        VB_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, k1, k2, i1, i2, (int)n, 0, 64, ctx->stream));
+        VB_TRY(hipStreamSynchronize(ctx->stream));
+        VB_TRY(hipFree(tmp)); tmp = nullptr;
+        tb = 0;
+        VB_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb, k2, ukeys, counts, d_runs, (int)n, ctx->stream));
+        VB_TRY(hipMalloc(&tmp, tb ? tb : 16));
+        VB_TRY(hipcub::DeviceRunLengthEncode::Encode(tmp, tb, k2, ukeys, counts, d_runs, (int)n, ctx->stream));
+        int runs = 0;
+        VB_TRY(hipMemcpyAsync(&runs, d_runs, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        VB_TRY(hipStreamSynchronize(ctx->stream));
+        VB_TRY(hipFree(tmp)); tmp = nullptr;
+        nu = runs;
+        // segment starts (exclusive scan of counts) and compacted positions of the kept voxels
+        VB_TRY(hipMemsetAsync(counts + nu, 0, 4, ctx->stream));
+        tb = 0;
+        VB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, counts, seg, (int)nu + 1, ctx->stream));
+        VB_TRY(hipMalloc(&tmp, tb ? tb : 16));
+        VB_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tb, counts, seg, (int)nu + 1, ctx->stream));
+        hipLaunchKernelGGL(k_keep_flags, dim3((unsigned)((nu + 256) / 256)), dim3(256), 0, ctx->stream, counts, nu, min_points, flags);
+        VB_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tb, flags, flags, (int)nu + 1, ctx->stream));
+        uint32_t kept = 0;
+        VB_TRY(hipMemcpyAsync(&kept, flags + nu, 4, hipMemcpyDeviceToHost, ctx->stream));
+        VB_TRY(hipStreamSynchronize(ctx->stream));
+        VB_TRY(hipFree(tmp)); tmp = nullptr;
+        nk = kept;
+    }
+    {
+        const size_t kk = (size_t)(nk > 0 ? nk : 1);
+        VB_TRY(hipMalloc(&t->st_mean, 8 * 3 * kk)); VB_TRY(hipMalloc(&t->st_cov, 8 * 9 * kk));
+        VB_TRY(hipMalloc(&t->st_norm, 8 * 3 * kk)); VB_TRY(hipMalloc(&t->st_icov, 8 * 9 * kk));
+        VB_TRY(hipMalloc(&t->st_counts, 8 * kk)); VB_TRY(hipMalloc(&t->st_keys, 8 * kk));
+        if (nu > 0) {
+            hipLaunchKernelGGL(k_voxel_stats<T>, dim3((unsigned)((nu + 127) / 128)), dim3(128), 0, ctx->stream, d_xyz, i2,
+                               ukeys, counts, seg, flags, nu, min_points, t->st_mean, t->st_cov, t->st_norm, t->st_icov,
+                               t->st_counts, t->st_keys);
+            VB_TRY(hipGetLastError());
+            VB_TRY(hipStreamSynchronize(ctx->stream));
+        }
+        t->n = nk;
+    }
+done:
+#undef VB_TRY
+    void *ptrs[] = {k1, k2, ukeys, i1, i2, counts, seg, flags, d_runs, tmp};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (st != PCR_OK) return st;
+    return pcr_voxel_target_finish(ctx, t, voxel_size);
+}
+
+extern "C" pcr_status pcr_target_voxels_create(pcr_context *ctx, const void *xyz, int xyz_is_f64, int64_t n,
+                                               double voxel_size, int min_points, pcr_target **out) {
+    PCR_REQUIRE(ctx && out, "NULL argument");
+    PCR_REQUIRE(n >= 0 && (xyz || n == 0), "bad point array");
+    PCR_REQUIRE(n < ((int64_t)1 << 31), "at most 2^31-1 points per target");
+    PCR_REQUIRE(voxel_size > 0, "voxel_size must be positive");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t elem = xyz_is_f64 ? 8 : 4;
+    void *d_xyz = nullptr;
+    HIP_TRY(hipMalloc(&d_xyz, elem * 3 * (size_t)(n > 0 ? n : 1)));
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(d_xyz, xyz, elem * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    pcr_target *t = new pcr_target();
+    t->ctx = ctx; t->is_voxel = 1;
+    pcr_status s = xyz_is_f64 ? voxel_build<double>(ctx, (const double *)d_xyz, n, voxel_size, min_points, t)
+                              : voxel_build<float>(ctx, (const float *)d_xyz, n, voxel_size, min_points, t);
+    (void)hipFree(d_xyz);
+    if (s != PCR_OK) { pcr_target_destroy(t); return s; }
+    *out = t;
+    return PCR_OK;
+}

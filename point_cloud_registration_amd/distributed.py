@@ -1,0 +1,79 @@
+"""Multi-GPU: one process per GPU, the scan sharded across ranks, one 29-double all-reduce of the
+normal equations per iteration.  The reference is single-process.
+
+Two transports for the same 232-byte exchange:
+* ``in_library=True`` (GPU runs): RCCL inside libpcr_hip.so, on the kernel's own HIP stream,
+  between the finalize kernel and the device-to-host copy -- no Python, no torch in the loop.
+  The RCCL unique id is distributed once through ``torch.distributed`` (any backend).
+* ``in_library=False``: ``torch.distributed.all_reduce`` on a host tensor (``gloo``); used by the
+  CPU tests of the N>1 path and available as a fallback.
+"""
+
+import os
+
+import numpy as np
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous, balanced [lo, hi) of an n-point scan for ``rank`` of ``world``."""
+    base, rem = divmod(int(n), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_scan(source, rank, world):
+    lo, hi = shard_bounds(source.shape[0], rank, world)
+    return source[lo:hi]
+
+
+class Communicator:
+    def __init__(self, ctx=None, in_library=True, group=None):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed must be initialised (torchrun / init_process_group)")
+        self._dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.ctx = ctx
+        self.in_library = bool(in_library) and ctx is not None
+        if self.in_library:
+            from . import _capi
+            uid = [_capi.comm_unique_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0, group=group)
+            ctx.comm_init(uid[0], self.world, self.rank)
+
+    def allreduce(self, out29):
+        """Host-side sum of the 29 doubles over all ranks (gloo path)."""
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(out29, dtype=np.float64).copy())
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+        return t.numpy()
+
+    def barrier(self):
+        self._dist.barrier(group=self.group)
+
+    def close(self):
+        if self.in_library and self.ctx is not None:
+            self.ctx.comm_destroy()
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from torchrun's environment (RANK / WORLD_SIZE / MASTER_*)."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    kw = {}
+    if backend == "nccl":
+        dev = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(dev)
+        try:
+            kw["device_id"] = torch.device("cuda", dev)
+        except Exception:
+            pass
+    dist.init_process_group(backend=backend, **kw)

@@ -1,0 +1,335 @@
+"""Parity of the HIP hot path (through the C ABI) against the CPU oracle and the golden vectors.
+
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+Tolerances (BASELINE.json north_star): J^T J within 1e-5 relative (max|dH|/max|H|) and SE(3)
+within 1e-4 rad / 1e-4 m of the REFERENCE; against the ORACLE (same arithmetic definitions,
+only the summation order differs) the bar is 1e-10.  Correspondence indices are bit-exact.
+"""
+
+import numpy as np
+import pytest
+
+from conftest import rel_H
+
+pytestmark = pytest.mark.gpu
+
+TOL_REF = 1e-5
+TOL_ORC = 1e-10
+NAMES = ["icp", "plane", "vplane", "ndt"]
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from point_cloud_registration_amd import _capi
+    assert _capi.device_count() >= 1, "no MI355X visible"
+    return _capi
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def ctx(capi):
+    return capi.get_context(0)
+
+
+def kind_of(capi, name):
+    return {"icp": capi.ICP, "plane": capi.PLANE, "vplane": capi.VPLANE, "ndt": capi.NDT}[name]
+
+
+def make_targets(capi, orc, ctx, target, normals, voxel_size):
+    """GPU targets + matching oracle targets.  Voxel statistics come from the oracle here so the
+    test isolates the per-iteration kernels; the GPU voxel build has its own tests."""
+    o_pts = orc.TargetPoints(target, normals=normals)
+    o_vox = orc.TargetVoxels(target, voxel_size)
+    g_pts = capi.Target.points(ctx, np.asarray(target, np.float32), normals)
+    g_vox = capi.Target.voxels_from_stats(ctx, o_vox.mean, o_vox.norm, o_vox.icov, voxel_size)
+    return ({"icp": g_pts, "plane": g_pts, "vplane": g_vox, "ndt": g_vox},
+            {"icp": o_pts, "plane": o_pts, "vplane": o_vox, "ndt": o_vox})
+
+
+def check_against(capi, orc, gt, ot, name, T, src, max_dist, scan=None, tol=TOL_ORC):
+    scan = scan or capi.Scan(gt[name].ctx, src)
+    out = capi.linearize(gt[name], scan, kind_of(capi, name), T, max_dist)
+    H, g, e2, cnt = capi.unpack29(out)
+    Ho, go, e2o, cnto = orc.calc_H_g_e2(kind_of(capi, name), ot[name], T, src, max_dist, with_count=True)
+    assert cnt == cnto
+    assert rel_H(H, Ho) < tol, (name, rel_H(H, Ho))
+    assert rel_H(g, go) < tol * 100, (name, rel_H(g, go))       # g cancels: looser relative bar
+    assert abs(e2 - e2o) <= tol * max(abs(e2o), 1e-30) * 10
+    return H, g, e2
+
+
+# ----------------------------------------------------------------------------- NN seam
+def test_nn_query_bit_exact_small(capi, orc, ctx, g2):
+    st = orc.transform(g2["T"], g2["source"])
+    tgt = capi.Target.points(ctx, g2["target"])
+    d, i = tgt.nn_query(st)
+    do, io = orc.nn_brute(g2["target"], st)
+    assert np.array_equal(i, io)
+    assert np.array_equal(d, do)
+    # bounded: beyond r_max -> -1 / inf (scipy's distance_upper_bound convention)
+    d, i = tgt.nn_query(st, r_max=0.8)
+    keep = do < 0.8
+    assert np.array_equal(i[keep], io[keep]) and np.all(i[~keep] == -1) and np.all(np.isinf(d[~keep]))
+    # golden (reference KD-tree) agreement up to float32 rounding of the transform
+    assert (i[keep] == g2["nn_idx"][keep]).mean() > 0.999
+
+
+@pytest.mark.parametrize("cell", [0.0, 0.05, 0.3, 2.0])
+def test_nn_query_random_clouds(capi, orc, ctx, cell):
+    rng = np.random.default_rng(5)
+    tgt = rng.uniform(-3, 3, (20000, 3)).astype(np.float32)
+    tgt[:500] = tgt[500:1000]                       # exact duplicates -> exact ties, smaller index wins
+    q = np.vstack([rng.uniform(-3.5, 3.5, (3000, 3)), rng.uniform(-30, 30, (200, 3)),
+                   tgt[:300].astype(np.float64)]).astype(np.float32)
+    t = capi.Target.points(ctx, tgt, cell_hint=cell)
+    d, i = t.nn_query(q)
+    do, io = orc.nn_brute(tgt, q)
+    assert np.array_equal(i, io)
+    assert np.array_equal(d, do)
+
+
+def test_nn_query_centroids_f64(capi, orc, ctx, g2):
+    vox = orc.TargetVoxels(g2["target"], float(g2["voxel_size"]))
+    t = capi.Target.voxels_from_stats(ctx, vox.mean, vox.norm, vox.icov, float(g2["voxel_size"]))
+    st = orc.transform(g2["T"], g2["source"])
+    d, i = t.nn_query(st)
+    do, io = orc.nn_brute_f64(vox.mean, st)
+    assert np.array_equal(i, io) and np.array_equal(d, do)
+
+
+def test_nn_degenerate_targets(capi, orc, ctx):
+    one = np.array([[1.0, 2.0, 3.0]], np.float32)
+    t = capi.Target.points(ctx, one)
+    q = np.array([[0, 0, 0], [1, 2, 3], [100, -50, 7]], np.float32)
+    d, i = t.nn_query(q)
+    do, io = orc.nn_brute(one, q)
+    assert np.array_equal(i, io) and np.array_equal(d, do)
+    flat = np.zeros((100, 3), np.float32)           # all points identical: zero-extent bounding box
+    t = capi.Target.points(ctx, flat)
+    d, i = t.nn_query(q)
+    assert np.all(i == 0)
+
+
+# ----------------------------------------------------------------------------- hot path
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("tag", ["I", "T"])
+def test_linearize_reference_fixture(capi, orc, ctx, g1, name, tag):
+    gt, ot = make_targets(capi, orc, ctx, g1["target"], g1["plane_normals"], float(g1["voxel_size"]))
+    T = np.eye(4) if tag == "I" else g1["T"]
+    H, g, e2 = check_against(capi, orc, gt, ot, name, T, g1["source"], float(g1["max_dist"]))
+    assert rel_H(H, g1[f"{tag}_{name}_H"]) < TOL_REF
+    assert rel_H(g, g1[f"{tag}_{name}_g"]) < TOL_REF
+    assert abs(e2 - g1[f"{tag}_{name}_e2"]) < TOL_REF * max(1.0, abs(g1[f"{tag}_{name}_e2"]))
+
+
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("variant", [0, 1])
+def test_linearize_masked_multivoxel(capi, orc, ctx, g2, name, variant):
+    gt, ot = make_targets(capi, orc, ctx, g2["target"], g2["plane_normals"], float(g2["voxel_size"]))
+    ctx.set_variant(variant)
+    try:
+        H, g, e2 = check_against(capi, orc, gt, ot, name, g2["T"], g2["source"], float(g2["max_dist"]))
+    finally:
+        ctx.set_variant(0)
+    assert rel_H(H, g2[f"T_{name}_H"]) < TOL_REF
+    assert rel_H(g, g2[f"T_{name}_g"]) < 5 * TOL_REF
+    assert abs(e2 - g2[f"T_{name}_e2"]) < 5 * TOL_REF * abs(g2[f"T_{name}_e2"])
+
+
+def test_icp_quirk_flag(capi, orc, ctx, g1):
+    gt, ot = make_targets(capi, orc, ctx, g1["target"], g1["plane_normals"], 1.0)
+    scan = capi.Scan(ctx, g1["source"])
+    q = capi.unpack29(capi.linearize(gt["icp"], scan, capi.ICP, g1["T"], 2.0, capi.FLAG_ICP_RR_QUIRK))
+    c = capi.unpack29(capi.linearize(gt["icp"], scan, capi.ICP, g1["T"], 2.0, 0))
+    assert rel_H(q[1], g1["T_icp_g"]) < TOL_REF
+    _, gc, _ = orc.calc_H_g_e2(orc.ICP, ot["icp"], g1["T"], g1["source"], 2.0, flags=0)
+    assert rel_H(c[1], gc) < 1e-9
+    assert np.max(np.abs(q[1][3:] - c[1][3:])) > 1e-3
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_linearize_street_200k(capi, orc, ctx, name):
+    """Mid-size: 200 k-point street target, 60 k scan, oracle via its exact grid search."""
+    from point_cloud_registration_amd.synthetic import street, perturbed_scan
+    target = street(200_000, seed=3)
+    scan, T_true = perturbed_scan(target, 60_000, seed=4)
+    rng = np.random.default_rng(0)
+    normals = rng.normal(size=target.shape).astype(np.float32)
+    normals /= np.linalg.norm(normals, axis=1, keepdims=True)
+    gt, ot = make_targets(capi, orc, ctx, target, normals, 1.0)
+    T = np.eye(4); T[:3, 3] = [0.02, -0.01, 0.03]
+    check_against(capi, orc, gt, ot, name, T, scan, 2.0, tol=1e-9)
+    check_against(capi, orc, gt, ot, name, T_true, scan, 0.25, tol=1e-9)   # tight gate: many masked
+
+
+def test_scan_order_independence(capi, ctx, g2):
+    """Morton sorting the scan only permutes the summation order."""
+    tgt = capi.Target.points(ctx, g2["target"], g2["plane_normals"])
+    a = capi.linearize(tgt, capi.Scan(ctx, g2["source"]), capi.PLANE, g2["T"], 0.8)
+    b = capi.linearize(tgt, capi.Scan(ctx, g2["source"], flags=capi.FLAG_NO_SCAN_SORT), capi.PLANE, g2["T"], 0.8)
+    perm = np.random.default_rng(1).permutation(g2["source"].shape[0])
+    c = capi.linearize(tgt, capi.Scan(ctx, g2["source"][perm]), capi.PLANE, g2["T"], 0.8)
+    assert np.allclose(a, b, rtol=1e-12, atol=1e-12) and np.allclose(a, c, rtol=1e-12, atol=1e-12)
+    assert a[28] == b[28] == c[28]
+    # determinism: same inputs, same bits
+    assert np.array_equal(a, capi.linearize(tgt, capi.Scan(ctx, g2["source"]), capi.PLANE, g2["T"], 0.8))
+
+
+# ----------------------------------------------------------------------------- classes / align
+def _classes(g, **kw):
+    import point_cloud_registration_amd as pcr
+    md, vs, k = float(g["max_dist"]), float(g["voxel_size"]), int(g["k"])
+    return {"icp": pcr.ICP(max_dist=md, **kw), "plane": pcr.PlaneICP(max_dist=md, k=k, **kw),
+            "vplane": pcr.VPlaneICP(voxel_size=vs, max_dist=md, **kw), "ndt": pcr.NDT(voxel_size=vs, max_dist=md, **kw)}
+
+
+def _pose_close(T, ref, tol=1e-4):
+    dR = T[:3, :3] @ ref[:3, :3].T
+    ang = np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))
+    return np.max(np.abs(T[:3, 3] - ref[:3, 3])) < tol and ang < tol
+
+
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("native", [False, True])
+def test_align_matches_reference(g2, name, native):
+    """Reference-style usage: cls(...).set_target(target); align(scan) -> SE(3) within 1e-4 of the
+    reference's own result, same number of Gauss-Newton iterations."""
+    obj = _classes(g2, native_loop=native)[name]
+    with pytest.raises(ValueError):
+        obj.align(g2["source"])                           # target not set (registration.py:80-81)
+    if name == "plane":
+        obj.set_target(g2["target"], None, None)
+        # normals estimated on the GPU: agree with the reference's where well conditioned
+        dots = np.abs(np.sum(obj.normal * g2["plane_normals"], axis=1))
+        assert np.mean(dots > 0.999) > 0.9
+        obj.set_target(g2["target"], obj.kdtree, g2["plane_normals"])   # then pin them for the pose check
+    else:
+        obj.set_target(g2["target"])
+    assert obj.is_target_set()
+    T = obj.align(g2["source"], np.eye(4))
+    assert obj.last_iterations == g2[f"align_{name}_T"].shape[0]
+    assert _pose_close(T, g2[f"align_{name}_final"])
+    H, g, e2 = obj.calc_H_g_e2(g2["T"], g2["source"])
+    assert rel_H(H, g2[f"T_{name}_H"]) < TOL_REF
+
+
+def test_zero_correspondences_is_singular(g2):
+    """Quirk Q7: nothing passes the gate -> H = 0 -> numpy.linalg.LinAlgError."""
+    import point_cloud_registration_amd as pcr
+    far = (g2["source"] + np.float32(500.0)).astype(np.float32)
+    for native in (False, True):
+        icp = pcr.ICP(max_dist=0.5, native_loop=native)
+        icp.set_target(g2["target"])
+        H, g, e2 = icp.calc_H_g_e2(np.eye(4), far)
+        assert not H.any() and not g.any() and e2 == 0
+        with pytest.raises(np.linalg.LinAlgError):
+            icp.align(far)
+    empty = np.zeros((0, 3), np.float32)
+    H, g, e2 = icp.calc_H_g_e2(np.eye(4), empty)
+    assert not H.any()
+
+
+def test_kdtree_seam(capi, orc, g2):
+    import point_cloud_registration_amd as pcr
+    tree = pcr.KDTree(g2["target"])
+    st = orc.transform(g2["T"], g2["source"])
+    d, i = tree.query(st)
+    do, io = orc.nn_brute(g2["target"], st)
+    assert d.dtype == np.float32 and np.array_equal(i, io) and np.array_equal(d, do)
+    d5, i5 = tree.query(st[:500], k=5)
+    dk, ik = orc.knn_brute(g2["target"], st[:500], 5)
+    assert d5.shape == (500, 5) and np.array_equal(i5, ik) and np.array_equal(d5, dk)
+
+
+def test_profile_counters(capi, ctx, g2):
+    tgt = capi.Target.points(ctx, g2["target"], g2["plane_normals"])
+    scan = capi.Scan(ctx, g2["source"])
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    for _ in range(5):
+        capi.linearize(tgt, scan, capi.PLANE, g2["T"], 0.8)
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    assert prof["linearize"][0] == 5 and prof["linearize"][1] > 0
+    assert prof["finalize"][0] == 5
+
+
+def test_rccl_single_rank(capi, ctx, g2):
+    """The RCCL exchange step with a 1-rank communicator: same sums as without."""
+    tgt = capi.Target.points(ctx, g2["target"], g2["plane_normals"])
+    scan = capi.Scan(ctx, g2["source"])
+    a = capi.linearize(tgt, scan, capi.PLANE, g2["T"], 0.8)
+    ctx.comm_init(capi.comm_unique_id(), 1, 0)
+    try:
+        b = capi.linearize(tgt, scan, capi.PLANE, g2["T"], 0.8)
+    finally:
+        ctx.comm_destroy()
+    assert np.array_equal(a, b)
+
+
+# ----------------------------------------------------------------------------- set_target side
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("vs", [0.5, 1.0])
+def test_voxel_build_gpu(capi, orc, ctx, g3, dt, vs):
+    """VoxelGrid.set_points + calc_icov on the GPU vs the reference's own numbers."""
+    tag = f"{dt}_vs{vs}"
+    pts = g3[f"points_{dt}"]
+    t = capi.Target.voxels(ctx, pts, vs, 10)
+    st = t.voxel_stats()
+    counts = g3[f"{tag}_counts"]
+    keep = counts >= 10
+    assert np.array_equal(st["keys"], g3[f"{tag}_uniq"][keep])          # integer work: bit-exact
+    assert np.array_equal(st["counts"], counts[keep])
+    assert np.allclose(st["mean"], g3[f"{tag}_mean"], rtol=0, atol=1e-12)
+    assert np.allclose(st["cov"], g3[f"{tag}_cov"], rtol=1e-10, atol=1e-15)
+    assert np.allclose(st["icov"], g3[f"{tag}_icov"], rtol=1e-7, atol=0)
+    ev = g3[f"{tag}_evals"]
+    ok = (ev[:, 1] - ev[:, 0]) > 1e-3 * ev[:, 2]
+    dots = np.abs(np.sum(st["norm"] * g3[f"{tag}_norm"], axis=1))
+    assert np.all(dots[ok] > 1 - 1e-8)
+    # and bit-level agreement with the oracle's restatement of the same sums
+    o = orc.voxel_build(pts, vs, 10)
+    assert np.array_equal(st["mean"], o["mean"]) and np.array_equal(st["cov"], o["cov"])
+    assert np.allclose(st["icov"], orc.calc_icov(o["cov"]), rtol=1e-13, atol=0)
+
+
+def test_voxel_build_edge_cases(capi, ctx):
+    rng = np.random.default_rng(2)
+    # negative coordinates, voxels below min_points dropped, one huge voxel
+    pts = np.vstack([rng.uniform(-5, 5, (3000, 3)), rng.uniform(0.1, 0.9, (5000, 3)) + [-3, -2, -4]]).astype(np.float32)
+    t = capi.Target.voxels(ctx, pts, 1.0, 10)
+    st = t.voxel_stats(("counts", "keys", "mean"))
+    from point_cloud_registration_amd.voxel import get_keys
+    keys = get_keys(pts, 1.0)
+    u, c = np.unique(keys, return_counts=True)
+    assert np.array_equal(st["keys"], u[c >= 10]) and np.array_equal(st["counts"], c[c >= 10])
+    assert st["counts"].max() >= 5000
+    # nothing survives the filter -> empty target, zero correspondences
+    t0 = capi.Target.voxels(ctx, pts[:50], 0.01, 10)
+    assert t0.size() == 0
+    out = capi.linearize(t0, capi.Scan(ctx, pts[:100]), capi.VPLANE, np.eye(4), 2.0)
+    assert not out.any()
+
+
+@pytest.mark.parametrize("k", [5, 15])
+def test_knn_and_normals_gpu(capi, orc, ctx, g6, k):
+    pts = g6["points"]
+    t = capi.Target.points(ctx, pts)
+    d, i = t.knn_query(pts, k)
+    do, io = orc.knn_brute(pts, pts, k)
+    assert np.array_equal(i, io) and np.array_equal(d, do)
+    n_gpu = t.estimate_normals(k, compat=True)
+    n_orc = orc.normals_from_knn(pts, io, compat=True)
+    dots = np.abs(np.sum(n_gpu.astype(np.float64) * n_orc, axis=1))
+    assert np.mean(dots > 1 - 1e-6) > 0.995             # same float32 covariance, same eigen-solver
+    dref = np.abs(np.sum(n_gpu * g6[f"normals_k{k}"], axis=1))
+    assert np.mean(dref > 0.999) > 0.9                  # vs the reference (float32 LAPACK eigh)
+    n64 = t.estimate_normals(k, compat=False)
+    d64 = np.abs(np.sum(n64.astype(np.float64) * orc.normals_from_knn(pts, io, compat=False), axis=1))
+    assert np.mean(d64 > 1 - 1e-6) > 0.995
+    assert np.allclose(np.linalg.norm(n_gpu, axis=1), 1, atol=1e-5)
