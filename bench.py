@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Headline benchmark: M-correspondences/s of the registration hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config plane_b01|icp_b01|vplane_10m|ndt_10m|plane_100m]
+
+A "step" is ONE pass of the hot path -- one ``calc_H_g_e2``: float32 transform of the whole
+scan shard, exact nearest-neighbour search against the target, the ``dist < max_dist`` gate,
+residuals + Jacobians, and the reduction to the 6x6 Gauss-Newton normal equations (29 doubles
+back on the host; with N > 1 GPUs an RCCL all-reduce of those 29 doubles sits in between).
+Default workload = BASELINE.json configs[1]: Point-to-Plane ICP, B-01 stand-in target
+(``street(1_060_000, seed=0)``, the .pcd itself is absent from the reference checkout) vs a
+perturbed full-size scan; steps walk along a recorded Gauss-Newton trajectory.
+
+Multi-GPU (``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...``): one
+process per GPU, the target replicated, every rank owns a scan shard of the SAME size (weak
+scaling), no data-path collective besides the 232-byte all-reduce.
+
+Rank 0 prints one JSON line (contract in the task statement) with ``roofline`` (HIP-event kernel
+time measured here, live) and ``cpu_baseline`` (the CPU oracle on this box's host cores, bounded
+sample, N = 1 only).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling ~6300
+B_ALG = {"icp": 24, "plane": 36, "vplane": 36, "ndt": 48}     # bytes / scan point / pass
+
+CONFIGS = {
+    # name: (kind, target points, scan points per GPU, voxel_size, description)
+    "plane_b01": ("plane", 1_060_000, 1_060_000, None,
+                  "Point-to-Plane ICP (PlaneICP, k=15 normals), B-01 stand-in street(1.06M) vs perturbed scan"),
+    "icp_b01": ("icp", 1_060_000, 1_060_000, None, "Point-to-Point ICP, B-01 stand-in street(1.06M) vs perturbed scan"),
+    "plane_b01_100k": ("plane", 1_060_000, 100_000, None,
+                       "Point-to-Plane ICP, B-01 stand-in, reference-harness 100k scan"),
+    "vplane_10m": ("vplane", 10_000_000, 10_000_000, 0.5, "VPlaneICP voxel_size=0.5, synthetic 10M-pt cloud"),
+    "ndt_10m": ("ndt", 10_000_000, 10_000_000, 1.0, "NDT voxel_size=1.0, synthetic 10M-pt cloud"),
+    "plane_100m": ("plane", 100_000_000, 12_500_000, None,
+                   "Point-to-Plane ICP, synthetic 100M-pt target, 12.5M scan points per GPU"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="plane_b01", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-passes", type=int, default=3)
+    ap.add_argument("--variant", type=int, default=None, help="0 fused kernel, 1 NN + reduce kernels")
+    return ap.parse_args()
+
+
+def make_cloud(n, seed):
+    from point_cloud_registration_amd.synthetic import street, street_tiled
+    return street(n, seed=seed) if n <= 2_000_000 else street_tiled(n, seed=seed)
+
+
+def main():
+    args = parse()
+    import torch                                   # first: one HIP runtime / one RCCL per process
+    from point_cloud_registration_amd import _capi
+    from point_cloud_registration_amd import distributed as pdist
+    from point_cloud_registration_amd.synthetic import perturbed_scan
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node "
+                             f"{args.gpus} bench.py --gpus {args.gpus} ...` (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
+    dev = local % torch.cuda.device_count()
+    torch.cuda.set_device(dev)
+
+    kind_name, n_target, n_scan, voxel_size, desc = CONFIGS[args.config]
+    kind = {"icp": _capi.ICP, "plane": _capi.PLANE, "vplane": _capi.VPLANE, "ndt": _capi.NDT}[kind_name]
+    max_dist = 2.0
+
+    ctx = _capi.get_context(dev)
+    if args.variant is not None:
+        ctx.set_variant(args.variant)
+    comm = None
+    if world > 1:
+        pdist.init_from_env("nccl")
+        comm = pdist.Communicator(ctx, in_library=True)
+
+    # ---- workload (synthetic; same target on every rank, own scan shard per rank) -------------
+    t_setup = time.perf_counter()
+    target = make_cloud(n_target, seed=0)
+    scan, T_true = perturbed_scan(target, n_scan if n_scan < n_target else None, seed=2 + rank)
+    if kind_name in ("icp", "plane"):
+        tgt = _capi.Target.points(ctx, target)
+        if kind_name == "plane":
+            tgt.estimate_normals(15, compat=True, want=False)      # reference default k=15 (plane_icp.py:14)
+    else:
+        tgt = _capi.Target.voxels(ctx, target, voxel_size, 10)
+    sc = _capi.Scan(ctx, scan)
+    info = tgt.index_info()
+    # a real Gauss-Newton trajectory to walk along (same on every rank: the sums are all-reduced)
+    T_fin, iters, trace = _capi.align(tgt, sc, kind, np.eye(4), 30, 1e-3, max_dist, want_trace=True)
+    traj = [trace[i, :16].reshape(4, 4).copy() for i in range(iters)]
+    pose_err = float(np.linalg.norm(T_fin[:3, 3] - T_true[:3, 3]))
+    t_setup = time.perf_counter() - t_setup
+
+    def step(k):
+        return _capi.linearize(tgt, sc, kind, traj[k % len(traj)], max_dist)
+
+    def sync_all():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    # With torch.cuda initialised the interpreter tracks ~1e6 objects and a generation-2 garbage
+    # collection costs 35-50 ms -- a hundred passes' worth -- whenever the allocation counter trips
+    # (measured: tools/latency_probe.py).  Collect now, keep the collector out of the timed region.
+    import gc
+    gc.collect()
+    gc.disable()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    sync_all()
+    t0 = time.perf_counter()
+    out = None
+    step_t = []
+    for k in range(args.steps):
+        ts = time.perf_counter()
+        out = step(k)
+        step_t.append(time.perf_counter() - ts)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    gc.enable()
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if os.environ.get("PCR_BENCH_DEBUG"):
+        print("per-step ms:", " ".join(f"{t * 1e3:.2f}" for t in step_t), file=sys.stderr)
+    if rank == 0:
+        units = world * sc.n * args.steps                   # correspondences searched, whole job
+        value = units / elapsed / 1e6
+        kern = {k: {"launches": v[0], "avg_ms": v[1] / v[0]} for k, v in prof.items() if v[0]}
+        # dominant kernel(s) of one pass: everything that touches the scan / target
+        hot_ms = sum(kern[k]["avg_ms"] for k in ("linearize", "nn", "reduce") if k in kern)
+        alg_bytes = B_ALG[kind_name] * sc.n                 # per launch (one pass over this rank's shard)
+        achieved = alg_bytes / (hot_ms * 1e-3) / 1e9
+        traffic = None
+        pmc_file = os.path.join(REPO, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc_file):
+            try:
+                traffic = json.load(open(pmc_file)).get(args.config, {}).get("hbm_bytes_per_pass")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "M-correspondences/sec, %s calc_H_g_e2 on the B-01 stand-in (1.06 M pts)" % kind_name
+                      if "b01" in args.config else "M-correspondences/sec, %s calc_H_g_e2" % kind_name,
+            "value": round(value, 3), "unit": "Mcorr/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "iterations_per_sec": round(args.steps / elapsed, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "accumulate_dtype": "f64", "data": "synthetic",
+            "config": {"workload": args.config, "description": desc, "kind": kind_name,
+                       "target_points": int(n_target), "scan_points_per_gpu": int(sc.n),
+                       "max_dist": max_dist, "voxel_size": voxel_size, "parallelism": f"scan-shard x{world}",
+                       "nn_index": {"cell": info["cell"], "dims": info["dims"], "occupied_cells": info["occupied"]},
+                       "gauss_newton_iters_to_converge": iters, "pose_error_m": round(pose_err, 6),
+                       "correspondences_last_step": int(out[28]), "setup_s": round(t_setup, 2)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "kernel": "+".join(k for k in ("linearize", "nn", "reduce") if k in kern),
+                         "kernel_ms": round(hot_ms, 5), "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "bytes_per_point": B_ALG[kind_name]},
+            "kernels": {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 5)} for k, v in kern.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(kind_name, target, scan, tgt, traj, max_dist, voxel_size,
+                                                args.cpu_passes)
+        print(json.dumps(line), flush=True)
+    if comm is not None:
+        torch.distributed.barrier()
+        comm.close()
+        torch.distributed.destroy_process_group()
+
+
+def cpu_baseline(kind_name, target, scan, gpu_target, traj, max_dist, voxel_size, passes):
+    """The CPU oracle (a port of the reference's NumPy path to C + OpenMP) on this box's host cores:
+    the same calc_H_g_e2 on a bounded sample of the same workload."""
+    from oracle import oracle as orc
+    cap = 1_060_000                                   # bound the CPU work to ~10-30 s
+    src = scan[:cap]
+    tgt_pts = target
+    t0 = time.perf_counter()
+    if kind_name in ("icp", "plane"):
+        normals = gpu_target.get_normals() if kind_name == "plane" else None   # same normals as the GPU run
+        ot = orc.TargetPoints(tgt_pts, normals=normals, cell=0.5)
+    else:
+        ot = orc.TargetVoxels(tgt_pts, voxel_size)
+    t_build = time.perf_counter() - t0
+    kind = {"icp": orc.ICP, "plane": orc.PLANE, "vplane": orc.VPLANE, "ndt": orc.NDT}[kind_name]
+    orc.calc_H_g_e2(kind, ot, traj[0], src[:10000], max_dist)            # warm-up
+    t0 = time.perf_counter()
+    for k in range(passes):
+        orc.calc_H_g_e2(kind, ot, traj[k % len(traj)], src, max_dist)
+    dt = time.perf_counter() - t0
+    return {"value": round(src.shape[0] * passes / dt / 1e6, 4), "unit": "Mcorr/s",
+            "cores": orc.max_threads(), "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": f"{passes} passes of the same calc_H_g_e2 over {src.shape[0]} scan points "
+                      f"(oracle/pcr_oracle.c, OpenMP, exact grid NN); index build {t_build:.2f} s excluded"}
+
+
+if __name__ == "__main__":
+    main()

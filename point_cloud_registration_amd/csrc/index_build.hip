@@ -47,12 +47,20 @@ __global__ void __launch_bounds__(256) k_bbox(const T *__restrict__ xyz, int64_t
             hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
         }
     }
+    // one atomic per block and component (thousands of waves hammering six words serialise badly)
+    __shared__ float slo[4][3], shi[4][3];
+    const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            atomicMin(&box[a], f2ord(lo[a]));
-            atomicMax(&box[3 + a], f2ord(hi[a]));
-        }
+        for (int a = 0; a < 3; ++a) { slo[wave][a] = lo[a]; shi[wave][a] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        const float l = fminf(fminf(slo[0][a], slo[1][a]), fminf(slo[2][a], slo[3][a]));
+        const float h = fmaxf(fmaxf(shi[0][a], shi[1][a]), fmaxf(shi[2][a], shi[3][a]));
+        atomicMin(&box[a], f2ord(l));
+        atomicMax(&box[3 + a], f2ord(h));
     }
 }
 
@@ -64,7 +72,7 @@ static pcr_status device_bbox(pcr_context *ctx, const T *d_xyz, int64_t n, float
     HIP_TRY(hipMemcpyAsync(d_box, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
     if (n > 0) {
         int64_t nb = (n + 255) / 256;
-        if (nb > 4096) nb = 4096;
+        if (nb > 1024) nb = 1024;
         hipLaunchKernelGGL(k_bbox<T>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_xyz, n, d_box);
     }
     unsigned h[6];

@@ -168,18 +168,27 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
     return __hiloint2double(hi, lo);
 }
 
+// One halving step: lanes whose `MASK` bit is clear keep components [0, HALF), the others keep
+// [HALF, 2*HALF); each lane adds its partner's copy of what it keeps.  HALF and MASK are template
+// constants so every acc[] index is static (a runtime-indexed array would live in scratch).
+template <int HALF, int MASK>
+__device__ __forceinline__ void fold_step(double *acc, int lane) {
+    const bool upper = (lane & MASK) != 0;
+#pragma unroll
+    for (int i = 0; i < HALF; ++i) {
+        const double send = upper ? acc[i] : acc[i + HALF];
+        const double keep = upper ? acc[i + HALF] : acc[i];
+        acc[i] = keep + shfl_xor_f64(send, MASK);
+    }
+}
+
 // After the call lane l holds the wave-wide sum of component (l >> 1) in acc[0].
 __device__ __forceinline__ void wave_fold32(double *acc, int lane) {
-#pragma unroll
-    for (int half = 16, mask = 32; half >= 1; half >>= 1, mask >>= 1) {
-        const bool upper = (lane & mask) != 0;
-#pragma unroll
-        for (int i = 0; i < half; ++i) {
-            const double send = upper ? acc[i] : acc[i + half];
-            const double keep = upper ? acc[i + half] : acc[i];
-            acc[i] = keep + shfl_xor_f64(send, mask);
-        }
-    }
+    fold_step<16, 32>(acc, lane);
+    fold_step<8, 16>(acc, lane);
+    fold_step<4, 8>(acc, lane);
+    fold_step<2, 4>(acc, lane);
+    fold_step<1, 2>(acc, lane);
     acc[0] += shfl_xor_f64(acc[0], 1);
 }
 
@@ -451,7 +460,19 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
         if (cs != PCR_OK) return cs;
     }
     HIP_TRY(hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(double) * 29, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // The pass takes a fraction of a millisecond: poll the stream instead of sleeping in
+    // hipStreamSynchronize (whose wake-up latency can exceed the whole pass), then fall back.
+    {
+        hipError_t q = hipErrorNotReady;
+        for (int spin = 0; spin < 200000 && (q = hipStreamQuery(ctx->stream)) == hipErrorNotReady; ++spin) {
+            __builtin_ia32_pause();
+        }
+        if (q == hipErrorNotReady) q = hipStreamSynchronize(ctx->stream);
+        if (q != hipSuccess) {
+            pcr_set_error("stream wait failed: %s", hipGetErrorString(q));
+            return PCR_ERR_HIP;
+        }
+    }
     for (int i = 0; i < 29; ++i) out[i] = ctx->h_out[i];
     return PCR_OK;
 }
