@@ -1,0 +1,162 @@
+"""Host-side logic of the drop-in classes (no GPU): the Gauss-Newton driver's control flow with
+the per-iteration sums supplied by the oracle, helpers, API surface."""
+
+import inspect
+
+import numpy as np
+import pytest
+
+import point_cloud_registration_amd as pcr
+from point_cloud_registration_amd import _capi, math_tools as mt
+from point_cloud_registration_amd.distributed import shard_bounds
+from oracle import oracle as orc
+
+KIND = {"icp": orc.ICP, "plane": orc.PLANE, "vplane": orc.VPLANE, "ndt": orc.NDT}
+
+
+def pack29(H, g, e2, cnt):
+    return np.concatenate([H[np.triu_indices(6)], g, [e2, cnt]])
+
+
+class _OracleBacked:
+    """Mixin: replaces the two GPU touch points of Registration with the CPU oracle so the HOST
+    logic (align loop, quirks Q3/Q4/Q7, solve, plus) can be exercised without a GPU."""
+
+    def _scan_for(self, source):
+        return np.ascontiguousarray(source, dtype=np.float32)
+
+    def _linearize(self, cur_T, scan):
+        H, g, e2, cnt = orc.calc_H_g_e2(self.ORC_KIND, self._otarget, cur_T, scan, self._max_dist(),
+                                        self._flags, with_count=True)
+        out = pack29(H, g, e2, cnt)
+        if self._comm is not None:
+            out = self._comm.allreduce(out)
+        H, g, e2, cnt = _capi.unpack29(out)
+        self.last_correspondences = cnt
+        return H, g, e2
+
+
+def make(name, g, **kw):
+    base = {"icp": pcr.ICP, "plane": pcr.PlaneICP, "vplane": pcr.VPlaneICP, "ndt": pcr.NDT}[name]
+    cls = type("Oracle" + base.__name__, (_OracleBacked, base), {"ORC_KIND": KIND[name]})
+    args = {"max_dist": float(g["max_dist"])}
+    if name in ("vplane", "ndt"):
+        args["voxel_size"] = float(g["voxel_size"])
+    obj = cls(**args, **kw)
+    if name in ("icp", "plane"):
+        obj._otarget = orc.TargetPoints(g["target"], normals=g["plane_normals"])
+    else:
+        obj._otarget = orc.TargetVoxels(g["target"], float(g["voxel_size"]))
+    return obj
+
+
+@pytest.mark.parametrize("name", list(KIND))
+def test_align_loop_matches_reference_trajectory(g2, name):
+    obj = make(name, g2)
+    with pytest.raises(ValueError, match="Target is not set"):
+        obj.align(g2["source"])
+    obj._is_target_set = True
+    T = obj.align(g2["source"], np.eye(4))
+    assert obj.last_iterations == g2[f"align_{name}_T"].shape[0]
+    final = g2[f"align_{name}_final"]
+    assert np.max(np.abs(T[:3, 3] - final[:3, 3])) < 1e-4
+    ang = np.arccos(np.clip((np.trace(T[:3, :3] @ final[:3, :3].T) - 1) / 2, -1, 1))
+    assert ang < 1e-4
+
+
+def test_convergence_test_precedes_update():
+    """Quirk Q4: when |dx| < tol the step is discarded (registration.py:106-111)."""
+    class Fake(_OracleBacked, pcr.ICP):
+        def _linearize(self, cur_T, scan):
+            self.calls += 1
+            return np.eye(6), -np.full(6, 1e-5), 0.0     # dx = 1e-5 * ones, |dx| < 1e-3
+    f = Fake(); f.calls = 0; f._is_target_set = True
+    T0 = np.eye(4); T0[0, 3] = 7.0
+    T = f.align(np.zeros((4, 3), np.float32), T0)
+    assert f.calls == 1 and np.array_equal(T, T0)
+
+
+def test_max_iter_and_singular():
+    class Fake(_OracleBacked, pcr.ICP):
+        def _linearize(self, cur_T, scan):
+            self.calls += 1
+            return np.eye(6), -np.array([0.1, 0, 0, 0, 0, 0.0]), 1.0
+    f = Fake(max_iter=4); f.calls = 0; f._is_target_set = True
+    T = f.align(np.zeros((4, 3), np.float32))
+    assert f.calls == 4 and abs(T[0, 3] - 0.4) < 1e-12 and f.last_iterations == 4
+
+    class Zero(_OracleBacked, pcr.ICP):
+        def _linearize(self, cur_T, scan):
+            return np.zeros((6, 6)), np.zeros(6), 0.0
+    z = Zero(); z._is_target_set = True
+    with pytest.raises(np.linalg.LinAlgError):          # quirk Q7
+        z.align(np.zeros((4, 3), np.float32))
+
+
+def test_api_surface_matches_reference_names():
+    """Same constructor keywords and defaults as the reference classes."""
+    sig = inspect.signature
+    assert list(sig(pcr.ICP.__init__).parameters)[:4] == ["self", "max_iter", "max_dist", "tol"]
+    assert sig(pcr.ICP.__init__).parameters["max_iter"].default == 30
+    assert sig(pcr.ICP.__init__).parameters["max_dist"].default == 2
+    assert sig(pcr.ICP.__init__).parameters["tol"].default == 1e-3
+    assert sig(pcr.PlaneICP.__init__).parameters["k"].default == 15
+    assert list(sig(pcr.PlaneICP.set_target).parameters) == ["self", "target", "kdree", "norm"]
+    assert list(sig(pcr.VPlaneICP.__init__).parameters)[:5] == ["self", "voxel_size", "max_iter", "max_dist", "tol"]
+    assert sig(pcr.NDT.__init__).parameters["voxel_size"].default == 1.0
+    assert sig(pcr.VoxelGrid.__init__).parameters["min_points"].default == 10
+    assert list(sig(pcr.Registration.align).parameters) == ["self", "source", "init_T", "verbose"]
+    for name in ["ICP", "PlaneICP", "VPlaneICP", "NDT", "KDTree", "VoxelGrid", "voxel_filter", "color_by_voxel",
+                 "estimate_normals", "get_norm_lines", "estimate_norm_with_tree", "makeRt", "expSO3", "makeT",
+                 "skews", "huber_weight", "plus", "transform_points", "skew_time_vector", "Registration"]:
+        assert hasattr(pcr, name), name
+    for cls in (pcr.ICP, pcr.PlaneICP, pcr.VPlaneICP, pcr.NDT):
+        assert not cls().is_target_set()
+        with pytest.raises(NotImplementedError):
+            cls().update_target(None)
+
+
+def test_math_helpers():
+    rng = np.random.default_rng(1)
+    v, w = rng.normal(size=(50, 3)), rng.normal(size=(50, 3))
+    assert np.allclose(mt.skew_time_vector(v, w), np.cross(v, w))
+    S = mt.skews(v)
+    assert np.allclose(np.einsum("nij,nj->ni", S, w), np.cross(v, w))
+    assert np.allclose(mt.skew(v[0]) @ w[0], np.cross(v[0], w[0]))
+    assert np.allclose(mt.skew2(v), np.einsum("nji,njk->ik", S, S))
+    T = mt.makeT(mt.expSO3(np.array([0.3, -0.2, 0.1])), np.array([1.0, 2.0, 3.0]))
+    R, t = mt.makeRt(T)
+    assert np.allclose(R @ R.T, np.eye(3)) and np.allclose(t, [1, 2, 3])
+    p = rng.normal(size=(10, 3))
+    assert np.allclose(mt.transform_points(T, p), p @ R.T + t)
+    assert np.allclose(mt.huber_weight(np.array([0.5, 2.0, 4.0]), 1.0), [1.0, 0.5, 0.25])
+    J = mt.numerical_derivative(lambda a: a ** 2, [np.array([1.0, 2.0])], 0)
+    assert np.allclose(J, np.diag([2.0, 4.0]), atol=1e-4)
+
+
+def test_voxel_host_utilities(g3):
+    pts = g3["points_f32"]
+    for vs in (0.5, 1.0):
+        assert np.array_equal(pcr.get_keys(pts, vs), g3[f"f32_vs{vs}_keys"])
+    f = pcr.voxel_filter(pts, 0.5)
+    uniq, inv = np.unique(g3["f32_vs0.5_keys"], return_inverse=True)
+    assert f.shape == (len(uniq), 3) and f.dtype == np.float32
+    assert np.allclose(f[inv[0]], pts[inv == inv[0]].astype(np.float64).mean(0), atol=1e-6)
+    c = pcr.color_by_voxel(pts, 0.5)
+    assert c["xyz"].shape == pts.shape and c["irgb"].dtype == np.uint32
+    lines = pcr.get_norm_lines(pts[:5], np.tile([0, 0, 1.0], (5, 1)).astype(np.float32), 0.1)
+    assert lines.shape == (10, 3) and np.allclose(lines[1::2] - lines[0::2], [0, 0, 0.1])
+
+
+def test_unpack29_and_sharding():
+    rng = np.random.default_rng(0)
+    A = rng.normal(size=(6, 6)); H = A + A.T
+    out = pack29(H, np.arange(6.0), 3.5, 17)
+    H2, g2, e2, cnt = _capi.unpack29(out)
+    assert np.allclose(H2, H) and np.allclose(g2, np.arange(6.0)) and e2 == 3.5 and cnt == 17
+    for n, w in ((10, 3), (7, 8), (1_060_000, 8), (0, 2)):
+        spans = [shard_bounds(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
