@@ -11,7 +11,7 @@
 
 #include <math.h>
 
-#include "pcr_internal.h"
+#include "nn_device.h"
 
 // ---- bounding box ---------------------------------------------------------------------------
 __device__ __forceinline__ unsigned f2ord(float f) {
@@ -233,7 +233,17 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
     HIP_TRY(hipMalloc(&d_cid, 4 * nn)); HIP_TRY(hipMalloc(&d_idx, 4 * nn));
     HIP_TRY(hipMalloc(&d_cid2, 4 * nn)); HIP_TRY(hipMalloc(&d_idx2, 4 * nn));
     PT *d_pts = nullptr;
-    HIP_TRY(hipMalloc(&d_pts, sizeof(PT) * nn));
+    HIP_TRY(hipMalloc(&d_pts, sizeof(PT) * (nn + PCR_PTS_PAD)));
+    {   // sentinel records behind the last point (see nn_scan_range): +inf coordinates, index ~0
+        PT pad[PCR_PTS_PAD];
+        for (int i = 0; i < PCR_PTS_PAD; ++i) {
+            pad[i].x = pad[i].y = pad[i].z = INFINITY;
+            if (sizeof(Real) == 4) { const uint32_t m = 0xffffffffu; memcpy(&pad[i].w, &m, 4); }
+            else { const long long m = 0xffffffffLL; memcpy(&pad[i].w, &m, 8); }
+        }
+        HIP_TRY(hipMemcpyAsync(d_pts + (size_t)n, pad, sizeof pad, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
     if (n > 0) {
         hipLaunchKernelGGL((k_cell_ids<Real, T>), dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, g, d_cid, d_idx, d_counts);
         PCR_TRY(sort_pairs<uint32_t>(ctx, d_cid, d_cid2, d_idx, d_idx2, n, bits_for(ncells)));

@@ -15,10 +15,9 @@
 // Roofline: HBM-bound gather/stream work, no dense contraction -> no MFMA.  Algorithmic bytes
 // per scan point: ICP 24, PlaneICP 36, VPlaneICP 36, NDT 48.
 //
-// Launch: 256-thread blocks (4 waves of 64).  Block b works on the contiguous chunk
-// v = (b % 8) * (nblocks / 8) + b / 8 of the sorted scan, so each of the 8 XCDs (block b runs
-// on XCD b % 8) sweeps one contiguous region of space and its private 4 MiB L2 holds that
-// region's target cells.  Per-lane accumulators are float64 (H entries reach 1e11 at 1e8
+// Launch: 256-thread blocks (4 waves of 64).  The sorted scan is split into 8 contiguous spans,
+// one per XCD (block b runs on XCD b % 8), so each XCD sweeps one region of space and its
+// private 4 MiB L2 holds that region's target cells (see TileIter).  Per-lane accumulators are float64 (H entries reach 1e11 at 1e8
 // points, float32 would lose the 1e-5 parity bar); the 32 sums are folded across the wave with
 // a halving butterfly (32 shuffles instead of 32 x 6), then across waves through LDS.
 #include "nn_device.h"
@@ -204,14 +203,22 @@ __device__ __forceinline__ void block_store_partials(double *acc, double *__rest
     }
 }
 
-__device__ __forceinline__ void block_chunk(const LinArgs &a, int64_t &lo, int64_t &hi) {
-    // XCD-aware contiguous chunks (nblocks is a multiple of 8)
-    const int per = a.nblocks >> 3;
-    const int v = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    const int64_t chunk = (((a.n + a.nblocks - 1) / a.nblocks) + 255) & ~(int64_t)255;
-    lo = (int64_t)v * chunk;
-    hi = lo + chunk < a.n ? lo + chunk : a.n;
-}
+// Work distribution: the sorted scan is cut into 8 contiguous spans, one per XCD (block b runs on
+// XCD b % 8, so each XCD's private L2 serves one region of space); inside a span the 256-point
+// tiles are dealt round-robin to that XCD's blocks, which evens out regions where the search is
+// slow (large residual offsets) without giving up the locality.
+struct TileIter {
+    int64_t base, end, stride;
+    __device__ __forceinline__ TileIter(const LinArgs &a) {
+        const int per = a.nblocks >> 3;                         // blocks per XCD
+        const int xcd = (int)(blockIdx.x & 7), bi = (int)(blockIdx.x >> 3);
+        const int64_t span = (((a.n + 7) >> 3) + 255) & ~(int64_t)255;
+        const int64_t lo = span * xcd;
+        end = lo + span < a.n ? lo + span : a.n;
+        base = lo + (int64_t)bi * 256 + threadIdx.x;
+        stride = (int64_t)per * 256;
+    }
+};
 
 // ---- variant 0: everything in one kernel ----------------------------------------------------
 template <int KIND>
@@ -219,9 +226,8 @@ __global__ void __launch_bounds__(256) k_linearize(const LinArgs a) {
     double acc[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-    int64_t lo, hi;
-    block_chunk(a, lo, hi);
-    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const TileIter it(a);
+    for (int64_t i = it.base; i < it.end; i += it.stride) {
         const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
         float tx, ty, tz;
         xform(a, x, y, z, tx, ty, tz);
@@ -244,9 +250,8 @@ __global__ void __launch_bounds__(256) k_linearize(const LinArgs a) {
 // ---- variant 1: NN kernel (few registers, high occupancy) + streaming reduce kernel ---------
 template <int VOXEL>
 __global__ void __launch_bounds__(256) k_nn_scan(const LinArgs a) {
-    int64_t lo, hi;
-    block_chunk(a, lo, hi);
-    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const TileIter it(a);
+    for (int64_t i = it.base; i < it.end; i += it.stride) {
         const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
         float tx, ty, tz;
         xform(a, x, y, z, tx, ty, tz);
@@ -270,9 +275,8 @@ __global__ void __launch_bounds__(256) k_reduce(const LinArgs a) {
     double acc[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-    int64_t lo, hi;
-    block_chunk(a, lo, hi);
-    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const TileIter it(a);
+    for (int64_t i = it.base; i < it.end; i += it.stride) {
         const uint32_t j = a.nn_j[i];
         if (j == PCR_NONE) continue;
         const float x = a.sx[i], y = a.sy[i], z = a.sz[i];

@@ -41,15 +41,33 @@ template <> struct RealTraits<double> {
 };
 
 template <typename Real, typename PT>
+__device__ __forceinline__ void nn_test(const PT &p, uint32_t j, Real qx, Real qy, Real qz,
+                                        Real &best, uint32_t &bj, uint32_t &borig) {
+    const Real dx = qx - (Real)p.x, dy = qy - (Real)p.y, dz = qz - (Real)p.z;
+    const Real d = (dx * dx + dy * dy) + dz * dz;
+    const uint32_t o = pt_orig(p);
+    // straight-line selects (bitwise, not short-circuit): no exec-mask juggling in the hot loop
+    const bool take = (d < best) | ((d == best) & (o < borig));
+    best = take ? d : best; bj = take ? j : bj; borig = take ? o : borig;
+}
+
+// The search is latency-bound (one L2 round trip per dependent load, ~500 cycles): candidates are
+// fetched four at a time so four loads are in flight per lane before the first compare.  A batch
+// may run up to 3 records past the end of the range: those are real points of the following cells
+// (testing an extra true candidate can only help), and the array carries PCR_PTS_PAD sentinel
+// records at +inf behind its last point, which never win a comparison.
+#define PCR_PTS_PAD 4
+template <typename Real, typename PT>
 __device__ __forceinline__ void nn_scan_range(const PT *__restrict__ pts, uint32_t s, uint32_t e,
                                               Real qx, Real qy, Real qz,
                                               Real &best, uint32_t &bj, uint32_t &borig) {
-    for (uint32_t j = s; j < e; ++j) {
-        const PT p = pts[j];
-        const Real dx = qx - (Real)p.x, dy = qy - (Real)p.y, dz = qz - (Real)p.z;
-        const Real d = (dx * dx + dy * dy) + dz * dz;
-        const uint32_t o = pt_orig(p);
-        if (d < best || (d == best && o < borig)) { best = d; bj = j; borig = o; }
+    for (uint32_t j = s; j < e; j += 4) {
+        const PT *__restrict__ b = pts + j;
+        const PT p0 = b[0], p1 = b[1], p2 = b[2], p3 = b[3];
+        nn_test<Real, PT>(p0, j, qx, qy, qz, best, bj, borig);
+        nn_test<Real, PT>(p1, j + 1, qx, qy, qz, best, bj, borig);
+        nn_test<Real, PT>(p2, j + 2, qx, qy, qz, best, bj, borig);
+        nn_test<Real, PT>(p3, j + 3, qx, qy, qz, best, bj, borig);
     }
 }
 
