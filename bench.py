@@ -68,6 +68,11 @@ def make_cloud(n, seed):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE JSON line: route everything else that libraries print there (RCCL's
+    # start-up banner, for one) to stderr by swapping the file descriptor until the final print
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch                                   # first: one HIP runtime / one RCCL per process
     from point_cloud_registration_amd import _capi
     from point_cloud_registration_amd import distributed as pdist
@@ -94,7 +99,8 @@ def main():
     if args.variant is not None:
         ctx.set_variant(args.variant)
     comm = None
-    if world > 1:
+    use_comm = world > 1 or bool(os.environ.get("PCR_BENCH_FORCE_COMM"))     # the latter: 1-rank self-test
+    if use_comm:
         pdist.init_from_env("nccl")
         comm = pdist.Communicator(ctx, in_library=True)
 
@@ -116,13 +122,16 @@ def main():
     pose_err = float(np.linalg.norm(T_fin[:3, 3] - T_true[:3, 3]))
     t_setup = time.perf_counter() - t_setup
 
+    host_reduce = comm is not None and not comm.in_library       # fallback transport (see distributed.py)
+
     def step(k):
-        return _capi.linearize(tgt, sc, kind, traj[k % len(traj)], max_dist)
+        o = _capi.linearize(tgt, sc, kind, traj[k % len(traj)], max_dist)
+        return comm.allreduce(o) if host_reduce else o
 
     def sync_all():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_comm:
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
@@ -149,7 +158,7 @@ def main():
     gc.enable()
     prof = ctx.profile_read()
     ctx.profile_enable(False)
-    if world > 1:
+    if use_comm:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -196,7 +205,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(kind_name, target, scan, tgt, traj, max_dist, voxel_size,
                                                 args.cpu_passes)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if comm is not None:
         torch.distributed.barrier()
         comm.close()

@@ -39,9 +39,28 @@ class Communicator:
         self.in_library = bool(in_library) and ctx is not None
         if self.in_library:
             from . import _capi
-            uid = [_capi.comm_unique_id() if self.rank == 0 else None]
+            ok = 1
+            try:
+                uid = [_capi.comm_unique_id() if self.rank == 0 else None]
+            except Exception as exc:                      # RCCL not loadable on rank 0
+                uid, ok = [None], 0
+                print(f"[pcr] RCCL unavailable ({exc}); using torch.distributed for the all-reduce", flush=True)
             dist.broadcast_object_list(uid, src=0, group=group)
-            ctx.comm_init(uid[0], self.world, self.rank)
+            if uid[0] is None:
+                ok = 0
+            else:
+                try:
+                    ctx.comm_init(uid[0], self.world, self.rank)
+                except Exception as exc:
+                    ok = 0
+                    print(f"[pcr] rank {self.rank}: in-library RCCL init failed ({exc})", flush=True)
+            # every rank must take the same path: agree on the minimum
+            flags = [None] * self.world
+            dist.all_gather_object(flags, ok, group=group)
+            if min(flags) == 0:
+                if ok:
+                    ctx.comm_destroy()
+                self.in_library = False
 
     def allreduce(self, out29):
         """Host-side sum of the 29 doubles over all ranks (gloo path)."""

@@ -1,0 +1,163 @@
+"""Full-size (BASELINE.json) cases on the GPU, checked through size-independent properties plus
+oracle spot checks: additivity over scan shards (the multi-GPU decomposition), permutation
+invariance, determinism, exactness of sampled correspondences, recovery of the known pose, and
+agreement of the whole Gauss-Newton run with the CPU oracle."""
+
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from point_cloud_registration_amd import _capi
+    assert _capi.device_count() >= 1
+    return _capi
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def b01(capi):
+    """B-01 stand-in (street 1.06 M) + full-size perturbed scan, PlaneICP normals from the GPU."""
+    from point_cloud_registration_amd.synthetic import street, perturbed_scan
+    ctx = capi.get_context(0)
+    target = street(1_060_000, seed=0)
+    scan, T_true = perturbed_scan(target, None, seed=2)
+    tgt = capi.Target.points(ctx, target)
+    normals = tgt.estimate_normals(15, compat=True)
+    return {"ctx": ctx, "target": target, "scan": scan, "T_true": T_true, "tgt": tgt, "normals": normals}
+
+
+def pose_err(T, ref):
+    dR = T[:3, :3] @ ref[:3, :3].T
+    return float(np.max(np.abs(T[:3, 3] - ref[:3, 3]))), float(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1)))
+
+
+@pytest.mark.parametrize("kind_name", ["icp", "plane"])
+def test_b01_shard_additivity_and_permutation(capi, b01, kind_name):
+    kind = {"icp": capi.ICP, "plane": capi.PLANE}[kind_name]
+    ctx, tgt, scan = b01["ctx"], b01["tgt"], b01["scan"]
+    T = np.eye(4); T[:3, 3] = [0.02, -0.01, 0.03]
+    full = capi.linearize(tgt, capi.Scan(ctx, scan), kind, T, 2.0)
+    assert full[28] > 0.99 * scan.shape[0]
+    from point_cloud_registration_amd.distributed import shard_scan
+    parts = sum(capi.linearize(tgt, capi.Scan(ctx, shard_scan(scan, r, 8)), kind, T, 2.0) for r in range(8))
+    assert parts[28] == full[28]                                   # counts: exact
+    assert np.allclose(parts, full, rtol=1e-11, atol=1e-9 * np.max(np.abs(full)))
+    perm = np.random.default_rng(0).permutation(scan.shape[0])
+    permuted = capi.linearize(tgt, capi.Scan(ctx, scan[perm]), kind, T, 2.0)
+    assert permuted[28] == full[28] and np.allclose(permuted, full, rtol=1e-11, atol=1e-9 * np.max(np.abs(full)))
+    again = capi.linearize(tgt, capi.Scan(ctx, scan), kind, T, 2.0)
+    assert np.array_equal(again, full)                             # deterministic reduction
+
+
+def test_b01_sampled_correspondences_are_exact(capi, orc, b01):
+    """4096 random transformed scan points: the GPU's neighbour is the exhaustive-search neighbour."""
+    rng = np.random.default_rng(3)
+    pick = rng.choice(b01["scan"].shape[0], 4096, replace=False)
+    T = np.eye(4); T[:3, 3] = [0.02, -0.01, 0.03]
+    q = orc.transform(T, b01["scan"][pick])
+    d, i = b01["tgt"].nn_query(q)
+    do, io = orc.nn_brute(b01["target"], q)
+    assert np.array_equal(i, io) and np.array_equal(d, do)
+    dk, ik = b01["tgt"].knn_query(q[:512], 15)
+    dko, iko = orc.knn_brute(b01["target"], q[:512], 15)
+    assert np.array_equal(ik, iko) and np.array_equal(dk, dko)
+
+
+def test_b01_plane_align_matches_oracle_and_truth(capi, orc, b01):
+    """The whole Gauss-Newton run at BASELINE config 1 size: GPU vs CPU oracle (same normals)."""
+    ctx, tgt, scan = b01["ctx"], b01["tgt"], b01["scan"]
+    sc = capi.Scan(ctx, scan)
+    T, iters, trace = capi.align(tgt, sc, capi.PLANE, np.eye(4), 30, 1e-3, 2.0, want_trace=True)
+    dt, dang = pose_err(T, b01["T_true"])
+    assert dt < 2e-3 and dang < 1e-4                                # noise-limited recovery of T_true
+    ot = orc.TargetPoints(b01["target"], normals=b01["normals"], cell=0.5)
+    otrace = []
+    To = orc.align(orc.PLANE, ot, scan, np.eye(4), 30, 1e-3, 2.0, trace=otrace)
+    assert len(otrace) == iters
+    dt, dang = pose_err(T, To)
+    assert dt < 1e-7 and dang < 1e-7                                # north-star bar is 1e-4 / 1e-4
+    for k, (cur, H, g, e2) in enumerate(otrace):
+        Hg, gg, e2g, _ = capi.unpack29(trace[k, 16:])
+        assert rel_H(Hg, H) < 1e-9 and abs(e2g - e2) < 1e-9 * abs(e2)
+
+
+def test_b01_harness_mode_icp(capi, b01):
+    """BASELINE config 0 shape: 100 k random subsample shifted by (0, 0, 0.3) + noise (the reference
+    harness, benchmark/test_data.py:21-44); align recovers the inverse shift."""
+    from point_cloud_registration_amd.synthetic import harness_scan
+    import point_cloud_registration_amd as pcr
+    scan = harness_scan(b01["target"], 100_000)
+    icp = pcr.ICP(max_iter=30, tol=1e-3, max_dist=2.0)
+    icp.set_target(b01["target"])
+    T = icp.align(scan, np.eye(4))
+    assert np.allclose(T[:3, 3], [0, 0, -0.3], atol=5e-3)
+    assert np.allclose(T[:3, :3], np.eye(3), atol=1e-3)
+    assert icp.last_correspondences == 100_000
+
+
+@pytest.fixture(scope="module")
+def street10m(capi):
+    from point_cloud_registration_amd.synthetic import street_tiled, perturbed_scan
+    target = street_tiled(10_000_000, seed=0)
+    scan, T_true = perturbed_scan(target, 2_000_000, seed=5)
+    return {"ctx": capi.get_context(0), "target": target, "scan": scan, "T_true": T_true}
+
+
+@pytest.mark.parametrize("kind_name,vs", [("vplane", 0.5), ("ndt", 1.0)])
+def test_10m_voxel_paths(capi, orc, street10m, kind_name, vs):
+    """BASELINE configs 2-3 size: 10 M-point target through the GPU voxel build; additivity over
+    shards, voxel-statistics invariants, sampled nearest-centroid exactness."""
+    kind = {"vplane": capi.VPLANE, "ndt": capi.NDT}[kind_name]
+    ctx, target, scan = street10m["ctx"], street10m["target"], street10m["scan"]
+    tgt = capi.Target.voxels(ctx, target, vs, 10)
+    st = tgt.voxel_stats(("mean", "counts", "norm", "icov", "cov"))
+    assert st["counts"].min() >= 10 and st["counts"].sum() <= target.shape[0]
+    assert np.allclose(np.linalg.norm(st["norm"], axis=1), 1.0, atol=1e-12)
+    assert np.all(np.abs(st["mean"]) <= np.abs(target).max(0) + 1e-6)
+    sel = np.linalg.cond(st["cov"][:2000]) < 1e8
+    prod = np.einsum("nij,njk->nik", st["cov"][:2000][sel], st["icov"][:2000][sel])
+    assert np.allclose(prod, np.eye(3), atol=1e-6)                 # icov really inverts cov
+    T = np.eye(4); T[:3, 3] = [0.02, -0.01, 0.03]
+    full = capi.linearize(tgt, capi.Scan(ctx, scan), kind, T, 2.0)
+    from point_cloud_registration_amd.distributed import shard_scan
+    parts = sum(capi.linearize(tgt, capi.Scan(ctx, shard_scan(scan, r, 4)), kind, T, 2.0) for r in range(4))
+    assert parts[28] == full[28] and np.allclose(parts, full, rtol=1e-11, atol=1e-9 * np.max(np.abs(full)))
+    q = orc.transform(T, scan[:2048])
+    d, i = tgt.nn_query(q)
+    do, io = orc.nn_brute_f64(st["mean"], q)
+    assert np.array_equal(i, io) and np.array_equal(d, do)
+    # min_points = 1 keeps every voxel: counts add up to N and the count-weighted centroid mean is
+    # the cloud mean
+    t1 = capi.Target.voxels(ctx, target[:2_000_000], vs, 1)
+    s1 = t1.voxel_stats(("mean", "counts"))
+    assert s1["counts"].sum() == 2_000_000
+    wmean = (s1["mean"] * s1["counts"][:, None]).sum(0) / 2_000_000
+    assert np.allclose(wmean, target[:2_000_000].astype(np.float64).mean(0), atol=1e-9)
+
+
+@pytest.mark.skipif(not os.environ.get("PCR_TEST_100M"), reason="set PCR_TEST_100M=1 (needs ~30 s of host data generation)")
+def test_100m_plane(capi):
+    """BASELINE config 4 size: 100 M-point target, 12.5 M-point scan shard."""
+    from point_cloud_registration_amd.synthetic import street_tiled, perturbed_scan
+    from point_cloud_registration_amd.distributed import shard_scan
+    ctx = capi.get_context(0)
+    target = street_tiled(100_000_000, seed=0)
+    scan, T_true = perturbed_scan(target, 12_500_000, seed=5)
+    normals = np.zeros_like(target); normals[:, 2] = 1
+    tgt = capi.Target.points(ctx, target, normals)
+    T = np.eye(4)
+    full = capi.linearize(tgt, capi.Scan(ctx, scan), capi.PLANE, T, 2.0)
+    parts = sum(capi.linearize(tgt, capi.Scan(ctx, shard_scan(scan, r, 8)), capi.PLANE, T, 2.0) for r in range(8))
+    assert parts[28] == full[28] and np.allclose(parts, full, rtol=1e-11, atol=1e-9 * np.max(np.abs(full)))
