@@ -128,6 +128,59 @@ __global__ void __launch_bounds__(256) k_gather_f64(const double *__restrict__ x
                           __longlong_as_double((long long)i));
 }
 
+// ---- empty-space field: Chebyshev distance (in cells) to the nearest occupied cell -----------------
+__global__ void __launch_bounds__(256) k_gap_init(const uint32_t *__restrict__ cs, int64_t ncells, uint8_t *gap) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c < ncells) gap[c] = cs[c + 1] != cs[c] ? 0 : 255;
+}
+
+// one dilation step: an unreached cell with a neighbour (26-connectivity) at distance t-1 is at
+// distance t.  In place and race-free: only value-255 cells are written, only value t-1 is tested.
+__global__ void __launch_bounds__(256) k_gap_step(uint8_t *gap, int nx, int ny, int nz, int t) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t ncells = (int64_t)nx * ny * nz;
+    if (c >= ncells || gap[c] != 255) return;
+    const int x = (int)(c % nx), y = (int)((c / nx) % ny), z = (int)(c / ((int64_t)nx * ny));
+    const uint8_t want = (uint8_t)(t - 1);
+    bool hit = false;
+    for (int dz = -1; dz <= 1 && !hit; ++dz) {
+        const int zz = z + dz;
+        if (zz < 0 || zz >= nz) continue;
+        for (int dy = -1; dy <= 1 && !hit; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= ny) continue;
+            const int64_t row = ((int64_t)zz * ny + yy) * nx;
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = x + dx;
+                if (xx >= 0 && xx < nx && gap[row + xx] == want) { hit = true; break; }
+            }
+        }
+    }
+    if (hit) gap[c] = (uint8_t)t;
+}
+
+__global__ void __launch_bounds__(256) k_gap_pack(uint32_t *cs, int64_t ncells, const uint8_t *__restrict__ gap) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncells) return;
+    const uint32_t g = gap[c] > PCR_GAP_MAX ? PCR_GAP_MAX : gap[c];
+    cs[c] |= g << PCR_GAP_SHIFT;
+}
+
+static pcr_status pack_gap_field(pcr_context *ctx, uint32_t *cs, int nx, int ny, int nz) {
+    const int64_t ncells = (int64_t)nx * ny * nz;
+    uint8_t *gap = nullptr;
+    HIP_TRY(hipMalloc(&gap, (size_t)ncells));
+    const unsigned nb = (unsigned)((ncells + 255) / 256);
+    hipLaunchKernelGGL(k_gap_init, dim3(nb), dim3(256), 0, ctx->stream, cs, ncells, gap);
+    for (int t = 1; t <= PCR_GAP_MAX; ++t)
+        hipLaunchKernelGGL(k_gap_step, dim3(nb), dim3(256), 0, ctx->stream, gap, nx, ny, nz, t);
+    hipLaunchKernelGGL(k_gap_pack, dim3(nb), dim3(256), 0, ctx->stream, cs, ncells, gap);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(gap));
+    return PCR_OK;
+}
+
 template <typename Real>
 static bool make_geom(const float lo[3], const float hi[3], double h, Geom<Real> *g, double *ncells) {
     g->ox = (Real)lo[0]; g->oy = (Real)lo[1]; g->oz = (Real)lo[2];
@@ -141,6 +194,7 @@ static bool make_geom(const float lo[3], const float hi[3], double h, Geom<Real>
     for (int a = 0; a < 3; ++a) { mag = fmax(mag, fabs((double)lo[a])); mag = fmax(mag, fabs((double)hi[a])); }
     const double eps = sizeof(Real) == 4 ? 1.2e-7 : 2.3e-16;
     g->slack = (Real)(16.0 * eps * (mag + h) + 1e-30);
+    g->cs_mask = 0xffffffffu;
     return true;
 }
 
@@ -253,6 +307,11 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
             hipLaunchKernelGGL(k_gather_f64, dim3(nb), dim3(256), 0, ctx->stream, (const double *)d_xyz, d_idx2, n, (PtD *)d_pts);
     }
     PCR_TRY(exclusive_scan_u32(ctx, d_counts, (int64_t)ncells + 1));
+    if (n > 0 && n < ((int64_t)1 << PCR_GAP_SHIFT)) {
+        PCR_TRY(pack_gap_field(ctx, d_counts, g.nx, g.ny, g.nz));
+        g.cs_mask = (1u << PCR_GAP_SHIFT) - 1u;
+        *geom = g;
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipFree(d_cid)); HIP_TRY(hipFree(d_idx)); HIP_TRY(hipFree(d_cid2)); HIP_TRY(hipFree(d_idx2));

@@ -93,16 +93,16 @@ __device__ __forceinline__ void knn_search(const Geom<float> &g, const PtF *__re
                         if (a > (float)xl) xl = (int)floorf(fminf(a, lim));
                         if (b < (float)xh) xh = (int)floorf(fmaxf(b, -lim));
                     }
-                    if (xl <= xh) knn_scan_range(L, pts, cs[row + xl], cs[row + xh + 1], qx, qy, qz, kth, kth_o);
+                    if (xl <= xh) knn_scan_range(L, pts, cs[row + xl] & g.cs_mask, cs[row + xh + 1] & g.cs_mask, qx, qy, qz, kth, kth_o);
                 } else {
                     const int xa = cx - k, xb = cx + k;
                     if (xa >= 0 && xa < g.nx) {
                         const float dxm = fmaxf((float)(k - 1) * g.h + fx - g.slack, 0.f);
-                        if (dyz2 + dxm * dxm <= kth) knn_scan_range(L, pts, cs[row + xa], cs[row + xa + 1], qx, qy, qz, kth, kth_o);
+                        if (dyz2 + dxm * dxm <= kth) knn_scan_range(L, pts, cs[row + xa] & g.cs_mask, cs[row + xa + 1] & g.cs_mask, qx, qy, qz, kth, kth_o);
                     }
                     if (xb >= 0 && xb < g.nx) {
                         const float dxm = fmaxf((float)k * g.h - fx - g.slack, 0.f);
-                        if (dyz2 + dxm * dxm <= kth) knn_scan_range(L, pts, cs[row + xb], cs[row + xb + 1], qx, qy, qz, kth, kth_o);
+                        if (dyz2 + dxm * dxm <= kth) knn_scan_range(L, pts, cs[row + xb] & g.cs_mask, cs[row + xb + 1] & g.cs_mask, qx, qy, qz, kth, kth_o);
                     }
                 }
             }

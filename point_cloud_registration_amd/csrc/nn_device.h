@@ -94,7 +94,13 @@ __device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restr
         const Real kr = RT::sqrt_rn(bound2) * g.inv_h + (Real)2;
         if (kr < (Real)kmax) kmax = (int)kr;
     }
-    for (int k = k0; k <= kmax; ++k) {
+    int kstart = k0;
+    if (k0 == 0 && g.cs_mask != 0xffffffffu) {
+        // empty-space skipping: the gap field of the query's own cell says how many rings are empty
+        const size_t own = ((size_t)cz * (size_t)g.ny + (size_t)cy) * (size_t)g.nx + (size_t)cx;
+        kstart = (int)(cs[own] >> PCR_GAP_SHIFT);
+    }
+    for (int k = kstart; k <= kmax; ++k) {
         if (k >= 1) {
             const Real lb = (Real)(k - 1) * g.h + fmin_ - g.slack;
             if (lb > (Real)0 && lb * lb > best) break;
@@ -124,18 +130,18 @@ __device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restr
                         if (b < (Real)xh) xh = (int)RT::floor_(fmax(b, -lim));
                     }
                     if (xl <= xh)
-                        nn_scan_range<Real, PT>(pts, cs[row + xl], cs[row + xh + 1], qx, qy, qz, best, bj, borig);
+                        nn_scan_range<Real, PT>(pts, cs[row + xl] & g.cs_mask, cs[row + xh + 1] & g.cs_mask, qx, qy, qz, best, bj, borig);
                 } else {                                    // interior row of the ring: its two end cells
                     const int xa = cx - k, xb = cx + k;
                     if (xa >= 0 && xa < g.nx) {
                         const Real dxm = fmax((Real)(k - 1) * g.h + fx - g.slack, (Real)0);
                         if (dyz2 + dxm * dxm <= best)
-                            nn_scan_range<Real, PT>(pts, cs[row + xa], cs[row + xa + 1], qx, qy, qz, best, bj, borig);
+                            nn_scan_range<Real, PT>(pts, cs[row + xa] & g.cs_mask, cs[row + xa + 1] & g.cs_mask, qx, qy, qz, best, bj, borig);
                     }
                     if (xb >= 0 && xb < g.nx) {
                         const Real dxm = fmax((Real)k * g.h - fx - g.slack, (Real)0);
                         if (dyz2 + dxm * dxm <= best)
-                            nn_scan_range<Real, PT>(pts, cs[row + xb], cs[row + xb + 1], qx, qy, qz, best, bj, borig);
+                            nn_scan_range<Real, PT>(pts, cs[row + xb] & g.cs_mask, cs[row + xb + 1] & g.cs_mask, qx, qy, qz, best, bj, borig);
                     }
                 }
             }

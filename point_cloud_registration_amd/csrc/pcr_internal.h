@@ -40,7 +40,13 @@ struct Geom {
     Real h, inv_h;     // cell edge and its reciprocal
     Real slack;        // conservative margin on every pruning bound (rounding of cell assignment)
     int nx, ny, nz;
+    // cell_start[c] = (gap << 28) | first point of cell c, where gap = min(15, Chebyshev distance in
+    // cells to the nearest occupied cell): rings closer than `gap` around c are empty and skipped.
+    // cs_mask = 0x0fffffff when the gap field is present (targets below 2^28 points), else ~0.
+    uint32_t cs_mask;
 };
+#define PCR_GAP_SHIFT 28
+#define PCR_GAP_MAX 15
 
 // points of a grid, cell-sorted: xyz + original index bit-cast into w
 typedef float4 PtF;
