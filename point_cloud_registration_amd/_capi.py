@@ -64,6 +64,7 @@ PROTOTYPES = {
     "pcr_profile_read": (C.c_int, [_vp, _i64p, _f64p]),
     "pcr_target_index_info": (C.c_int, [_vp, C.POINTER(C.c_double), _i64p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pcr_set_variant": (C.c_int, [_vp, C.c_int]),
+    "pcr_nn_counters": (C.c_int, [_vp, _vp, _f64p, C.c_double, _f64p]),
 }
 
 
@@ -342,6 +343,17 @@ def align(target, scan, kind, T_init, max_iter, tol, max_dist, flags=FLAG_ICP_RR
     if want_trace:
         return T, iters.value, trace[:iters.value]
     return T, iters.value
+
+
+def nn_counters(target, scan, T, max_dist):
+    """Search work counters for one pose (see include/pcr.h: pcr_nn_counters)."""
+    out = np.zeros(8)
+    check(lib().pcr_nn_counters(target.handle, scan.handle, np.ascontiguousarray(T, np.float64).reshape(16),
+                                float(max_dist), out))
+    names = ("rings", "rows_loaded", "rows_pruned", "candidates")
+    n = max(scan.n, 1)
+    return {**{k: out[i] / n for i, k in enumerate(names)},
+            **{"wave_" + k: out[4 + i] / n for i, k in enumerate(names)}}
 
 
 def unpack29(out):

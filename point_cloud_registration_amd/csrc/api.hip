@@ -67,6 +67,7 @@ extern "C" pcr_status pcr_context_destroy(pcr_context *ctx) {
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->h_out) (void)hipHostFree(ctx->h_out);
     if (ctx->d_nn_j) (void)hipFree(ctx->d_nn_j);
+    if (ctx->d_tile_ctr) (void)hipFree(ctx->d_tile_ctr);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PCR_OK;
@@ -160,7 +161,7 @@ static pcr_status upload(pcr_context *ctx, const T *host, size_t count, T **dev)
 
 static void target_free(pcr_target *t) {
     if (!t) return;
-    void *ptrs[] = {t->cell_start, t->pts, t->normals, t->means, t->vnorm, t->vicov,
+    void *ptrs[] = {t->cell_start, t->cell_seed, t->pts, t->normals, t->means, t->vnorm, t->vicov,
                     t->st_mean, t->st_cov, t->st_norm, t->st_icov, t->st_counts, t->st_keys};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete t;

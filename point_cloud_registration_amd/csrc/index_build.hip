@@ -129,20 +129,25 @@ __global__ void __launch_bounds__(256) k_gather_f64(const double *__restrict__ x
 }
 
 // ---- empty-space field: Chebyshev distance (in cells) to the nearest occupied cell -----------------
-__global__ void __launch_bounds__(256) k_gap_init(const uint32_t *__restrict__ cs, int64_t ncells, uint8_t *gap) {
+__global__ void __launch_bounds__(256) k_gap_init(const uint32_t *__restrict__ cs, int64_t ncells, uint8_t *gap,
+                                                  uint32_t *seed) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c < ncells) gap[c] = cs[c + 1] != cs[c] ? 0 : 255;
+    if (c >= ncells) return;
+    const bool occ = cs[c + 1] != cs[c];
+    gap[c] = occ ? 0 : 255;
+    seed[c] = occ ? cs[c] : 0xffffffffu;
 }
 
 // one dilation step: an unreached cell with a neighbour (26-connectivity) at distance t-1 is at
 // distance t.  In place and race-free: only value-255 cells are written, only value t-1 is tested.
-__global__ void __launch_bounds__(256) k_gap_step(uint8_t *gap, int nx, int ny, int nz, int t) {
+__global__ void __launch_bounds__(256) k_gap_step(uint8_t *gap, uint32_t *seed, int nx, int ny, int nz, int t) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t ncells = (int64_t)nx * ny * nz;
     if (c >= ncells || gap[c] != 255) return;
     const int x = (int)(c % nx), y = (int)((c / nx) % ny), z = (int)(c / ((int64_t)nx * ny));
     const uint8_t want = (uint8_t)(t - 1);
     bool hit = false;
+    int64_t from = 0;
     for (int dz = -1; dz <= 1 && !hit; ++dz) {
         const int zz = z + dz;
         if (zz < 0 || zz >= nz) continue;
@@ -152,11 +157,11 @@ __global__ void __launch_bounds__(256) k_gap_step(uint8_t *gap, int nx, int ny, 
             const int64_t row = ((int64_t)zz * ny + yy) * nx;
             for (int dx = -1; dx <= 1; ++dx) {
                 const int xx = x + dx;
-                if (xx >= 0 && xx < nx && gap[row + xx] == want) { hit = true; break; }
+                if (xx >= 0 && xx < nx && gap[row + xx] == want) { hit = true; from = row + xx; break; }
             }
         }
     }
-    if (hit) gap[c] = (uint8_t)t;
+    if (hit) { seed[c] = seed[from]; gap[c] = (uint8_t)t; }     // seed[from] was final one step ago
 }
 
 __global__ void __launch_bounds__(256) k_gap_pack(uint32_t *cs, int64_t ncells, const uint8_t *__restrict__ gap) {
@@ -166,14 +171,17 @@ __global__ void __launch_bounds__(256) k_gap_pack(uint32_t *cs, int64_t ncells, 
     cs[c] |= g << PCR_GAP_SHIFT;
 }
 
-static pcr_status pack_gap_field(pcr_context *ctx, uint32_t *cs, int nx, int ny, int nz) {
+static pcr_status pack_gap_field(pcr_context *ctx, uint32_t *cs, int nx, int ny, int nz, uint32_t **seed_out) {
     const int64_t ncells = (int64_t)nx * ny * nz;
     uint8_t *gap = nullptr;
+    uint32_t *seed = nullptr;
     HIP_TRY(hipMalloc(&gap, (size_t)ncells));
+    HIP_TRY(hipMalloc(&seed, 4 * (size_t)ncells));
+    *seed_out = seed;
     const unsigned nb = (unsigned)((ncells + 255) / 256);
-    hipLaunchKernelGGL(k_gap_init, dim3(nb), dim3(256), 0, ctx->stream, cs, ncells, gap);
+    hipLaunchKernelGGL(k_gap_init, dim3(nb), dim3(256), 0, ctx->stream, cs, ncells, gap, seed);
     for (int t = 1; t <= PCR_GAP_MAX; ++t)
-        hipLaunchKernelGGL(k_gap_step, dim3(nb), dim3(256), 0, ctx->stream, gap, nx, ny, nz, t);
+        hipLaunchKernelGGL(k_gap_step, dim3(nb), dim3(256), 0, ctx->stream, gap, seed, nx, ny, nz, t);
     hipLaunchKernelGGL(k_gap_pack, dim3(nb), dim3(256), 0, ctx->stream, cs, ncells, gap);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -195,6 +203,7 @@ static bool make_geom(const float lo[3], const float hi[3], double h, Geom<Real>
     const double eps = sizeof(Real) == 4 ? 1.2e-7 : 2.3e-16;
     g->slack = (Real)(16.0 * eps * (mag + h) + 1e-30);
     g->cs_mask = 0xffffffffu;
+    g->seed = nullptr;
     return true;
 }
 
@@ -235,7 +244,8 @@ static int bits_for(double ncells) {
 // prefix, stable radix sort by cell id, gather.
 template <typename Real, typename T, typename PT>
 static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double h, bool auto_h, Geom<Real> *geom,
-                             uint32_t **cell_start_out, PT **pts_out, int64_t *occupied_out) {
+                             uint32_t **cell_start_out, uint32_t **seed_out, PT **pts_out, int64_t *occupied_out) {
+    *seed_out = nullptr;
     PCR_REQUIRE(n < ((int64_t)1 << 31), "at most 2^31-1 points per target");
     HIP_TRY(hipSetDevice(ctx->device));
     float lo[3], hi[3];
@@ -308,9 +318,12 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
     }
     PCR_TRY(exclusive_scan_u32(ctx, d_counts, (int64_t)ncells + 1));
     if (n > 0 && n < ((int64_t)1 << PCR_GAP_SHIFT)) {
-        PCR_TRY(pack_gap_field(ctx, d_counts, g.nx, g.ny, g.nz));
+        uint32_t *seed = nullptr;
+        PCR_TRY(pack_gap_field(ctx, d_counts, g.nx, g.ny, g.nz, &seed));
         g.cs_mask = (1u << PCR_GAP_SHIFT) - 1u;
+        g.seed = seed;
         *geom = g;
+        *seed_out = seed;
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -327,11 +340,11 @@ pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n,
     const char *env = getenv("PCR_GRID_CELL");
     bool auto_h = !(cell_hint > 0);
     if (env && atof(env) > 0) { h = atof(env); auto_h = false; }
-    return build_grid<float, float, PtF>(ctx, d_xyz, n, h, auto_h, &t->gf, &t->cell_start, &t->pts, &t->occupied);
+    return build_grid<float, float, PtF>(ctx, d_xyz, n, h, auto_h, &t->gf, &t->cell_start, &t->cell_seed, &t->pts, &t->occupied);
 }
 
 pcr_status pcr_build_centroid_grid(pcr_context *ctx, const double *d_mean, int64_t n, double cell, pcr_target *t) {
-    return build_grid<double, double, PtD>(ctx, d_mean, n, cell, false, &t->gd, &t->cell_start, &t->means, &t->occupied);
+    return build_grid<double, double, PtD>(ctx, d_mean, n, cell, false, &t->gd, &t->cell_start, &t->cell_seed, &t->means, &t->occupied);
 }
 
 // ---- row permutations into cell-sorted order -------------------------------------------------

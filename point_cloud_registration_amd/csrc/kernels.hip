@@ -20,6 +20,8 @@
 // private 4 MiB L2 holds that region's target cells (see TileIter).  Per-lane accumulators are float64 (H entries reach 1e11 at 1e8
 // points, float32 would lose the 1e-5 parity bar); the 32 sums are folded across the wave with
 // a halving butterfly (32 shuffles instead of 32 x 6), then across waves through LDS.
+#include <string.h>
+
 #include "nn_device.h"
 
 struct LinArgs {
@@ -49,6 +51,7 @@ struct LinArgs {
     // variant 1: correspondences through HBM
     float *nn_dist;
     uint32_t *nn_j;
+    uint32_t *tile_ctr;   // 8 per-XCD tile counters (64 B apart) for k_nn_scan's dynamic scheduling
 };
 
 __device__ __forceinline__ void xform(const LinArgs &a, float x, float y, float z, float &tx, float &ty, float &tz) {
@@ -248,10 +251,23 @@ __global__ void __launch_bounds__(256) k_linearize(const LinArgs a) {
 }
 
 // ---- variant 1: NN kernel (few registers, high occupancy) + streaming reduce kernel ---------
+// The cost of a query varies by more than 10x with its distance to the surface, so waves pull
+// 64-point tiles from a per-XCD counter instead of owning a fixed share: every wave stays busy
+// until its XCD's span of the scan is exhausted (k_finalize re-zeroes the counters).
 template <int VOXEL>
 __global__ void __launch_bounds__(256) k_nn_scan(const LinArgs a) {
-    const TileIter it(a);
-    for (int64_t i = it.base; i < it.end; i += it.stride) {
+    const int xcd = (int)(blockIdx.x & 7);
+    const int64_t span = (((a.n + 7) >> 3) + 63) & ~(int64_t)63;
+    const int64_t lo = span * xcd;
+    const int64_t end = lo + span < a.n ? lo + span : a.n;
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(&a.tile_ctr[xcd * 16], 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        const int64_t i = lo + (int64_t)t * 64 + lane;
+        if (lo + (int64_t)t * 64 >= end) break;
+        if (i >= end) continue;
         const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
         float tx, ty, tz;
         xform(a, x, y, z, tx, ty, tz);
@@ -268,6 +284,34 @@ __global__ void __launch_bounds__(256) k_nn_scan(const LinArgs a) {
         }
         a.nn_j[i] = ok ? bj : PCR_NONE;
     }
+}
+
+// work counters of the search (instrumentation; same traversal as k_nn_scan<0>): out[0..3] = per-lane
+// sums of rings, rows loaded, rows pruned by arithmetic, candidates tested; out[4..7] = the same with
+// the per-WAVE maximum charged to all 64 lanes (what the SIMD actually executes under divergence)
+__global__ void __launch_bounds__(256) k_nn_counters(const LinArgs a, unsigned long long *out) {
+    const TileIter it(a);
+    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t i0 = it.base - threadIdx.x; i0 < it.end; i0 += it.stride) {
+        const int64_t i = i0 + threadIdx.x;
+        NNStats st = {0, 0, 0, 0};
+        if (i < it.end) {
+            const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
+            float tx, ty, tz;
+            xform(a, x, y, z, tx, ty, tz);
+            uint32_t bj, bo; float best;
+            nn_search<float, PtF, true>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo, &st);
+        }
+        uint32_t v[4] = {st.rings, st.rows_loaded, st.rows_pruned, st.cand};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint32_t m = v[c];
+            for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+            acc[c] += v[c];
+            acc[4 + c] += m;
+        }
+    }
+    for (int c = 0; c < 8; ++c) atomicAdd(&out[c], acc[c]);
 }
 
 template <int KIND>
@@ -290,6 +334,7 @@ __global__ void __launch_bounds__(256) k_reduce(const LinArgs a) {
 // ---- fold the per-block partials in a fixed order and emit the 29-vector ---------------------
 struct FinArgs {
     const double *partials;
+    uint32_t *tile_ctr;
     int nblocks;
     int kind;
     double R[9];
@@ -310,6 +355,7 @@ __global__ void __launch_bounds__(1024) k_finalize(const FinArgs f) {
         tot[threadIdx.x] = t;
     }
     __syncthreads();
+    if (threadIdx.x < 8) f.tile_ctr[threadIdx.x * 16] = 0;     // ready for the next k_nn_scan
     if (threadIdx.x == 0) {
         if (f.kind != PCR_ICP) {
             for (int i = 0; i < 29; ++i) f.out[i] = tot[i];
@@ -363,6 +409,14 @@ pcr_status pcr_ensure_scratch(pcr_context *ctx, int64_t n_points) {
         HIP_TRY(hipMalloc(&ctx->d_partials, sizeof(double) * 32 * (size_t)ctx->max_blocks));
         HIP_TRY(hipMalloc(&ctx->d_out, sizeof(double) * 32));
         HIP_TRY(hipHostMalloc(&ctx->h_out, sizeof(double) * 32, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&ctx->d_tile_ctr, sizeof(uint32_t) * 8 * 16));
+        HIP_TRY(hipMemsetAsync(ctx->d_tile_ctr, 0, sizeof(uint32_t) * 8 * 16, ctx->stream));
+        for (int v = 0; v < 2; ++v) {
+            int nb = 0;
+            hipError_t e = v == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<0>, 256, 0)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<1>, 256, 0);
+            ctx->nn_blocks_per_cu[v] = (e == hipSuccess && nb > 0) ? nb : 4;
+        }
     }
     if (ctx->variant == 1 && ctx->nn_cap < n_points) {
         if (ctx->d_nn_j) HIP_TRY(hipFree(ctx->d_nn_j));
@@ -420,7 +474,7 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
     a.flags = flags;
     a.nblocks = choose_blocks(ctx, s->n);
     a.partials = ctx->d_partials;
-    a.nn_dist = nullptr; a.nn_j = ctx->d_nn_j;
+    a.nn_dist = nullptr; a.nn_j = ctx->d_nn_j; a.tile_ctr = ctx->d_tile_ctr;
 
     ProfEvent ev;
     const dim3 grid(a.nblocks), block(256);
@@ -435,8 +489,16 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
         pcr_prof_end(ctx, &ev);
     } else {
         pcr_prof_begin(ctx, PCR_K_NN, &ev);
-        if (!t->is_voxel) hipLaunchKernelGGL(k_nn_scan<0>, grid, block, 0, ctx->stream, a);
-        else hipLaunchKernelGGL(k_nn_scan<1>, grid, block, 0, ctx->stream, a);
+        {   // exactly one resident generation of waves; they share the tiles dynamically
+            int64_t nb = (int64_t)ctx->num_cu * ctx->nn_blocks_per_cu[t->is_voxel ? 1 : 0];
+            const int64_t need = ((s->n + 63) / 64 + 3) / 4;
+            if (nb > need) nb = need;
+            nb = (nb + 7) & ~(int64_t)7;
+            if (nb < 8) nb = 8;
+            const dim3 nn_grid((unsigned)nb);
+            if (!t->is_voxel) hipLaunchKernelGGL(k_nn_scan<0>, nn_grid, block, 0, ctx->stream, a);
+            else hipLaunchKernelGGL(k_nn_scan<1>, nn_grid, block, 0, ctx->stream, a);
+        }
         pcr_prof_end(ctx, &ev);
         pcr_prof_begin(ctx, PCR_K_REDUCE, &ev);
         switch (kind) {
@@ -450,7 +512,7 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
     HIP_TRY(hipGetLastError());
 
     FinArgs f;
-    f.partials = ctx->d_partials; f.nblocks = a.nblocks; f.kind = kind; f.out = ctx->d_out;
+    f.partials = ctx->d_partials; f.tile_ctr = ctx->d_tile_ctr; f.nblocks = a.nblocks; f.kind = kind; f.out = ctx->d_out;
     for (int i = 0; i < 9; ++i) f.R[i] = a.R[i];
     pcr_prof_begin(ctx, PCR_K_FINALIZE, &ev);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, ctx->stream, f);
@@ -504,5 +566,35 @@ pcr_status pcr_run_nn(pcr_target *t, const float *d_q, int64_t m, double r_max, 
     }
     pcr_prof_end(ctx, &ev);
     HIP_TRY(hipGetLastError());
+    return PCR_OK;
+}
+
+// ---- instrumentation: search work counters for one pose (point targets) ------------------------
+extern "C" pcr_status pcr_nn_counters(pcr_target *t, pcr_scan *s, const double T[16], double max_dist, double out[8]) {
+    PCR_REQUIRE(t && s && T && out, "NULL argument");
+    PCR_REQUIRE(!t->is_voxel, "counters are implemented for point targets");
+    pcr_context *ctx = t->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    PCR_TRY(pcr_ensure_scratch(ctx, s->n));
+    LinArgs a;
+    memset(&a, 0, sizeof a);
+    a.sx = s->x; a.sy = s->y; a.sz = s->z; a.n = s->n;
+    a.gf = t->gf; a.pts = t->pts; a.cell_start = t->cell_start;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) a.r32[3 * i + j] = (float)T[4 * i + j];
+        a.t32[i] = (float)T[4 * i + 3];
+    }
+    const double bound = max_dist * (1.0 + 1e-6);
+    a.bound2_f = (float)(bound * bound);
+    a.nblocks = choose_blocks(ctx, s->n);
+    unsigned long long *d = nullptr, h[8];
+    HIP_TRY(hipMalloc(&d, sizeof h));
+    HIP_TRY(hipMemsetAsync(d, 0, sizeof h, ctx->stream));
+    hipLaunchKernelGGL(k_nn_counters, dim3(a.nblocks), dim3(256), 0, ctx->stream, a, d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d));
+    for (int i = 0; i < 8; ++i) out[i] = (double)h[i];
     return PCR_OK;
 }

@@ -32,11 +32,13 @@ template <typename Real> struct RealTraits;
 template <> struct RealTraits<float> {
     __device__ static __forceinline__ float inf() { return __int_as_float(0x7f800000); }
     __device__ static __forceinline__ float sqrt_rn(float x) { return __builtin_sqrtf(x); }   // correctly rounded (hipcc default); __fsqrt_rn maps to the NATIVE sqrt
+    __device__ static __forceinline__ float sqrt_fast(float x) { return __fsqrt_rn(x); }   // v_sqrt_f32, 1 ulp
     __device__ static __forceinline__ float floor_(float x) { return floorf(x); }
 };
 template <> struct RealTraits<double> {
     __device__ static __forceinline__ double inf() { return __longlong_as_double(0x7ff0000000000000LL); }
     __device__ static __forceinline__ double sqrt_rn(double x) { return __builtin_sqrt(x); }
+    __device__ static __forceinline__ double sqrt_fast(double x) { return __builtin_sqrt(x); }
     __device__ static __forceinline__ double floor_(double x) { return floor(x); }
 };
 
@@ -71,13 +73,16 @@ __device__ __forceinline__ void nn_scan_range(const PT *__restrict__ pts, uint32
     }
 }
 
+// Per-lane work counters, compiled in only for pcr_nn_counters (STATS = true).
+struct NNStats { uint32_t rings, rows_loaded, rows_pruned, cand; };
+
 // On return: bj = cell-sorted index of the nearest point (PCR_NONE if nothing closer than
 // sqrt(bound2)), best = its squared distance, borig = its original index.
-template <typename Real, typename PT>
+template <typename Real, typename PT, bool STATS = false>
 __device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restrict__ pts,
                                           const uint32_t *__restrict__ cs,
                                           Real qx, Real qy, Real qz, Real bound2,
-                                          Real &best, uint32_t &bj, uint32_t &borig) {
+                                          Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr) {
     typedef RealTraits<Real> RT;
     best = bound2; bj = PCR_NONE; borig = PCR_NONE;
     const Real lim = (Real)1.0e9;
@@ -99,12 +104,17 @@ __device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restr
         // empty-space skipping: the gap field of the query's own cell says how many rings are empty
         const size_t own = ((size_t)cz * (size_t)g.ny + (size_t)cy) * (size_t)g.nx + (size_t)cx;
         kstart = (int)(cs[own] >> PCR_GAP_SHIFT);
+        if (kstart > 0 && g.seed) {
+            const uint32_t j0 = g.seed[own];
+            if (j0 != PCR_NONE) nn_test<Real, PT>(pts[j0], j0, qx, qy, qz, best, bj, borig);
+        }
     }
     for (int k = kstart; k <= kmax; ++k) {
         if (k >= 1) {
             const Real lb = (Real)(k - 1) * g.h + fmin_ - g.slack;
             if (lb > (Real)0 && lb * lb > best) break;
         }
+        if (STATS) st->rings++;
         const int zlo = max(cz - k, 0), zhi = min(cz + k, g.nz - 1);
         const int ylo = max(cy - k, 0), yhi = min(cy + k, g.ny - 1);
         for (int z = zlo; z <= zhi; ++z) {
@@ -119,29 +129,39 @@ __device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restr
                 Real dym = dyc == 0 ? (Real)0 : (dyc > 0 ? (Real)dyc * g.h - fy : (Real)(-dyc - 1) * g.h + fy);
                 dym = fmax(dym - g.slack, (Real)0);
                 const Real dyz2 = dz2 + dym * dym;
-                if (dyz2 > best) continue;
+                if (dyz2 > best) { if (STATS) st->rows_pruned++; continue; }
                 const size_t row = ((size_t)z * (size_t)g.ny + (size_t)y) * (size_t)g.nx;
                 if (zshell || dyc == k || dyc == -k) {
                     int xl = max(cx - k, 0), xh = min(cx + k, g.nx - 1);
                     if (best < RT::inf()) {                 // clip the row to the remaining budget
-                        const Real xr = RT::sqrt_rn(best - dyz2) + g.slack;
+                        // approximate sqrt is fine here: the clip only has to be conservative
+                        const Real xr = RT::sqrt_fast(best - dyz2) * (Real)1.000002 + g.slack;
                         const Real a = (qx - xr - g.ox) * g.inv_h, b = (qx + xr - g.ox) * g.inv_h;
                         if (a > (Real)xl) xl = (int)RT::floor_(fmin(a, lim));
                         if (b < (Real)xh) xh = (int)RT::floor_(fmax(b, -lim));
                     }
-                    if (xl <= xh)
-                        nn_scan_range<Real, PT>(pts, cs[row + xl] & g.cs_mask, cs[row + xh + 1] & g.cs_mask, qx, qy, qz, best, bj, borig);
+                    if (xl <= xh) {
+                        const uint32_t s_ = cs[row + xl] & g.cs_mask, e_ = cs[row + xh + 1] & g.cs_mask;
+                        if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + 3) / 4) * 4; }
+                        nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
+                    }
                 } else {                                    // interior row of the ring: its two end cells
                     const int xa = cx - k, xb = cx + k;
                     if (xa >= 0 && xa < g.nx) {
                         const Real dxm = fmax((Real)(k - 1) * g.h + fx - g.slack, (Real)0);
-                        if (dyz2 + dxm * dxm <= best)
-                            nn_scan_range<Real, PT>(pts, cs[row + xa] & g.cs_mask, cs[row + xa + 1] & g.cs_mask, qx, qy, qz, best, bj, borig);
+                        if (dyz2 + dxm * dxm <= best) {
+                            const uint32_t s_ = cs[row + xa] & g.cs_mask, e_ = cs[row + xa + 1] & g.cs_mask;
+                            if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + 3) / 4) * 4; }
+                            nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
+                        }
                     }
                     if (xb >= 0 && xb < g.nx) {
                         const Real dxm = fmax((Real)k * g.h - fx - g.slack, (Real)0);
-                        if (dyz2 + dxm * dxm <= best)
-                            nn_scan_range<Real, PT>(pts, cs[row + xb] & g.cs_mask, cs[row + xb + 1] & g.cs_mask, qx, qy, qz, best, bj, borig);
+                        if (dyz2 + dxm * dxm <= best) {
+                            const uint32_t s_ = cs[row + xb] & g.cs_mask, e_ = cs[row + xb + 1] & g.cs_mask;
+                            if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + 3) / 4) * 4; }
+                            nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
+                        }
                     }
                 }
             }

@@ -44,6 +44,9 @@ struct Geom {
     // cells to the nearest occupied cell): rings closer than `gap` around c are empty and skipped.
     // cs_mask = 0x0fffffff when the gap field is present (targets below 2^28 points), else ~0.
     uint32_t cs_mask;
+    // seed[c] (cells with gap > 0 only matter): index of a point in the nearest occupied cell; its
+    // distance initialises the search bound of a query that lands in empty space
+    const uint32_t *seed;
 };
 #define PCR_GAP_SHIFT 28
 #define PCR_GAP_MAX 15
@@ -71,6 +74,8 @@ struct pcr_context {
     uint32_t *d_nn_j = nullptr;
     int64_t nn_cap = 0;
     int variant = 0;
+    uint32_t *d_tile_ctr = nullptr;     // per-XCD dynamic tile counters of k_nn_scan
+    int nn_blocks_per_cu[2] = {4, 4};   // resident 256-thread blocks per CU of k_nn_scan<0/1>
     // profiling
     bool prof_on = false;
     std::vector<ProfEvent> prof_events;
@@ -88,6 +93,7 @@ struct pcr_target {
     int64_t n = 0;           // points or kept voxels
     int64_t occupied = 0;    // occupied cells of the NN grid
     uint32_t *cell_start = nullptr;
+    uint32_t *cell_seed = nullptr;
     // point targets
     Geom<float> gf;
     PtF *pts = nullptr;        // cell-sorted
