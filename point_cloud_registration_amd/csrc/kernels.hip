@@ -338,16 +338,26 @@ struct FinArgs {
     int nblocks;
     int kind;
     double R[9];
-    double *out;   // 32 doubles
+    double *out;               // 32 doubles in HBM
+    double *host_out;          // optional: the same 29 values straight into pinned host memory ...
+    volatile uint32_t *host_flag;   // ... followed by this sequence number (host spins on it)
+    uint32_t seq;
 };
 
 __global__ void __launch_bounds__(1024) k_finalize(const FinArgs f) {
     __shared__ double part[32][33];
     __shared__ double tot[32];
     const int c = threadIdx.x & 31, r = threadIdx.x >> 5;     // 32 row-groups x 32 components
-    double s = 0.0;
-    for (int b = r; b < f.nblocks; b += 32) s += f.partials[(size_t)b * 32 + c];
-    part[r][c] = s;
+    // eight independent loads in flight per thread (a single dependent chain is pure latency)
+    double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b0 = r; b0 < f.nblocks; b0 += 256) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int b = b0 + 32 * u;
+            s8[u] += b < f.nblocks ? f.partials[(size_t)b * 32 + c] : 0.0;
+        }
+    }
+    part[r][c] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
     __syncthreads();
     if (threadIdx.x < 32) {
         double t = 0.0;
@@ -382,6 +392,11 @@ __global__ void __launch_bounds__(1024) k_finalize(const FinArgs f) {
             f.out[27] = tot[16]; f.out[28] = cnt;
         }
         f.out[29] = 0; f.out[30] = 0; f.out[31] = 0;
+        if (f.host_out) {
+            for (int i = 0; i < 29; ++i) f.host_out[i] = f.out[i];
+            __threadfence_system();
+            *f.host_flag = f.seq;
+        }
     }
 }
 
@@ -408,7 +423,9 @@ pcr_status pcr_ensure_scratch(pcr_context *ctx, int64_t n_points) {
         ctx->max_blocks = ctx->num_cu * 16;
         HIP_TRY(hipMalloc(&ctx->d_partials, sizeof(double) * 32 * (size_t)ctx->max_blocks));
         HIP_TRY(hipMalloc(&ctx->d_out, sizeof(double) * 32));
-        HIP_TRY(hipHostMalloc(&ctx->h_out, sizeof(double) * 32, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&ctx->h_out, sizeof(double) * 40, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(ctx->h_out, 0, sizeof(double) * 40);
+        HIP_TRY(hipHostGetDevicePointer((void **)&ctx->h_out_dev, ctx->h_out, 0));
         HIP_TRY(hipMalloc(&ctx->d_tile_ctr, sizeof(uint32_t) * 8 * 16));
         HIP_TRY(hipMemsetAsync(ctx->d_tile_ctr, 0, sizeof(uint32_t) * 8 * 16, ctx->stream));
         for (int v = 0; v < 2; ++v) {
@@ -476,6 +493,7 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
     a.partials = ctx->d_partials;
     a.nn_dist = nullptr; a.nn_j = ctx->d_nn_j; a.tile_ctr = ctx->d_tile_ctr;
 
+    if (ctx->variant == 1 && a.nblocks > ctx->num_cu * 4) a.nblocks = ctx->num_cu * 4;   // k_reduce streams: 4 blocks/CU
     ProfEvent ev;
     const dim3 grid(a.nblocks), block(256);
     if (ctx->variant == 0) {
@@ -514,6 +532,13 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
     FinArgs f;
     f.partials = ctx->d_partials; f.tile_ctr = ctx->d_tile_ctr; f.nblocks = a.nblocks; f.kind = kind; f.out = ctx->d_out;
     for (int i = 0; i < 9; ++i) f.R[i] = a.R[i];
+    // single GPU: k_finalize writes the result and a sequence number straight into pinned host memory
+    // (no copy command, no stream query); with a communicator the all-reduce sits in between
+    const bool direct = ctx->comm == nullptr && ctx->h_out_dev != nullptr;
+    volatile uint32_t *flag = (volatile uint32_t *)(ctx->h_out + 32);
+    f.host_out = direct ? ctx->h_out_dev : nullptr;
+    f.host_flag = direct ? (volatile uint32_t *)(ctx->h_out_dev + 32) : nullptr;
+    f.seq = ++ctx->seq;
     pcr_prof_begin(ctx, PCR_K_FINALIZE, &ev);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, ctx->stream, f);
     pcr_prof_end(ctx, &ev);
@@ -524,6 +549,20 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
         pcr_status cs = pcr_comm_allreduce29(ctx, ctx->d_out);
         pcr_prof_end(ctx, &ev);
         if (cs != PCR_OK) return cs;
+    }
+    if (direct) {
+        bool seen = false;
+        for (long spin = 0; spin < 4000000L; ++spin) {
+            if (*flag == f.seq) { seen = true; break; }
+            __builtin_ia32_pause();
+        }
+        if (!seen) {                                   // very long pass (or a fault): block, then re-check
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (*flag != f.seq) { pcr_set_error("finalize kernel did not report completion"); return PCR_ERR_HIP; }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        for (int i = 0; i < 29; ++i) out[i] = ctx->h_out[i];
+        return PCR_OK;
     }
     HIP_TRY(hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(double) * 29, hipMemcpyDeviceToHost, ctx->stream));
     // The pass takes a fraction of a millisecond: poll the stream instead of sleeping in

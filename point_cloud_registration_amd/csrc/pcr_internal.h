@@ -68,7 +68,9 @@ struct pcr_context {
     double *d_partials = nullptr;   // [max_blocks][32]
     int max_blocks = 0;
     double *d_out = nullptr;        // 32 doubles (29 used)
-    double *h_out = nullptr;        // pinned
+    double *h_out = nullptr;        // pinned + mapped: 32 doubles, then the completion sequence number
+    double *h_out_dev = nullptr;    // device-side address of h_out
+    uint32_t seq = 0;
     // variant-1 scratch (NN results in HBM)
     float *d_nn_dist = nullptr;
     uint32_t *d_nn_j = nullptr;
