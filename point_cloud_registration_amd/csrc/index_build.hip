@@ -111,6 +111,16 @@ __global__ void __launch_bounds__(256) k_count_nonzero(const uint32_t *__restric
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, (unsigned long long)local);
 }
 
+// occupied cells from the finished cell_start array (gap bits masked off)
+__global__ void __launch_bounds__(256) k_count_occupied(const uint32_t *__restrict__ cs, int64_t ncells, uint32_t mask,
+                                                        unsigned long long *out) {
+    unsigned local = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ncells; i += (int64_t)gridDim.x * 256)
+        local += (cs[i + 1] & mask) != (cs[i] & mask);
+    for (int off = 32; off >= 1; off >>= 1) local += __shfl_xor(local, off, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, (unsigned long long)local);
+}
+
 __global__ void __launch_bounds__(256) k_gather_f32(const float *__restrict__ xyz, const uint32_t *__restrict__ order,
                                                     int64_t n, PtF *out) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -284,6 +294,14 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
         break;
     }
     HIP_TRY(hipFree(d_nz));
+    if (auto_h && n > 0 && occupied > 0 && !capped) {
+        // fine adjustment: clouds are surfaces, so occupancy of occupied cells grows like h^2; aim at
+        // ~5 points per cell (measured optimum on MI355X: fewer candidates per ring-0 cell, still few rows)
+        const double occ = (double)n / (double)occupied;
+        double f = sqrt(5.0 / occ);
+        f = f < 0.70710678 ? 0.70710678 : (f > 1.41421356 ? 1.41421356 : f);
+        h *= f;
+    }
     // with the final h: ids + fresh histogram
     Geom<Real> g;
     make_geom<Real>(lo, hi, h, &g, &ncells);
@@ -329,6 +347,16 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipFree(d_cid)); HIP_TRY(hipFree(d_idx)); HIP_TRY(hipFree(d_cid2)); HIP_TRY(hipFree(d_idx2));
     // occupied cells for the final geometry
+    if (n > 0) {
+        unsigned long long *d_nz2 = nullptr, nz2 = 0;
+        HIP_TRY(hipMalloc(&d_nz2, sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(d_nz2, 0, sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(k_count_occupied, dim3(1024), dim3(256), 0, ctx->stream, d_counts, (int64_t)ncells, g.cs_mask, d_nz2);
+        HIP_TRY(hipMemcpyAsync(&nz2, d_nz2, sizeof nz2, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipFree(d_nz2));
+        occupied = (int64_t)nz2;
+    }
     *occupied_out = occupied;
     *cell_start_out = d_counts;
     *pts_out = d_pts;
