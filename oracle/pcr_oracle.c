@@ -19,8 +19,9 @@
  * tight, ~1e-12, and only summation order differs):
  *   - transform: T cast to float32, x' = ((R00*x + R01*y) + R02*z) + t0 in float32,
  *     no FMA contraction (build with -ffp-contract=off);
- *   - point NN: d2 = (dx*dx + dy*dy) + dz*dz in float32, dist = sqrtf(d2), ties broken
- *     by the smaller target index;  centroid NN: the same in float64;
+ *   - point NN: d2 = fma(dz, dz, fma(dy, dy, dx*dx)) in float32 (fmaf is exactly specified, so the
+ *     CPU and the GPU agree bit for bit), dist = sqrtf(d2), ties broken by the smaller target
+ *     index;  centroid NN: d2 = (dx*dx + dy*dy) + dz*dz in float64;
  *   - per-point residuals/Jacobians in float64 from the float32 inputs, all sums float64
  *     (the reference accumulates a few blocks in float32, quirk Q5: the oracle is the
  *     more accurate of the two and agrees with the reference to ~1e-6 of max|H|).
@@ -69,7 +70,7 @@ ORC_API void orc_transform(const double T[16], const float *src, int64_t n, floa
  * the mathematical definition (exhaustive search).                                   */
 static inline float d2f(const float *a, const float *b) {
     const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
-    return (dx * dx + dy * dy) + dz * dz;
+    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));     /* two fused multiply-adds, one rounding each */
 }
 static inline double d2d(const float *q, const double *c) {
     const double dx = (double)q[0] - c[0], dy = (double)q[1] - c[1], dz = (double)q[2] - c[2];

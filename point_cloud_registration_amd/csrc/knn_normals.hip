@@ -45,7 +45,7 @@ __device__ __forceinline__ void knn_scan_range(KnnList &L, const PtF *__restrict
     for (uint32_t j = s; j < e; ++j) {
         const PtF p = pts[j];
         const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-        const float d = (dx * dx + dy * dy) + dz * dz;
+        const float d = dist2_f32(dx, dy, dz);
         knn_offer(L, d, j, pt_orig(p), kth, kth_o);
     }
 }

@@ -16,9 +16,10 @@
 // the smaller original index (the oracle's rule), which makes the result independent of the
 // storage order.
 //
-// Arithmetic: d2 = (dx*dx + dy*dy) + dz*dz in Real (float for point targets, double for
-// centroids), no FMA contraction (the TU is compiled with -ffp-contract=off) -- identical to
-// oracle/pcr_oracle.c d2f / d2d, so both pick the same neighbour bit for bit.
+// Arithmetic: point targets d2 = fma(dz, dz, fma(dy, dy, dx*dx)) in float32 (explicit fused
+// multiply-adds, exactly specified); centroids d2 = (dx*dx + dy*dy) + dz*dz in float64 with no
+// contraction (the TU is compiled with -ffp-contract=off) -- identical to oracle/pcr_oracle.c
+// d2f / d2d, so both pick the same neighbour bit for bit.
 #pragma once
 
 #include "pcr_internal.h"
@@ -42,6 +43,12 @@ template <> struct RealTraits<double> {
     __device__ static __forceinline__ double floor_(double x) { return floor(x); }
 };
 
+// float32 squared distance, the one definition shared with oracle/pcr_oracle.c (d2f):
+// fma(dz, dz, fma(dy, dy, dx*dx)) -- two fused multiply-adds, each rounded once.
+__device__ __forceinline__ float dist2_f32(float dx, float dy, float dz) {
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+
 template <typename Real, typename PT>
 __device__ __forceinline__ void nn_test(const PT &p, uint32_t j, Real qx, Real qy, Real qz,
                                         Real &best, uint32_t &bj, uint32_t &borig) {
@@ -50,6 +57,21 @@ __device__ __forceinline__ void nn_test(const PT &p, uint32_t j, Real qx, Real q
     const uint32_t o = pt_orig(p);
     // straight-line selects (bitwise, not short-circuit): no exec-mask juggling in the hot loop
     const bool take = (d < best) | ((d == best) & (o < borig));
+    best = take ? d : best; bj = take ? j : bj; borig = take ? o : borig;
+}
+
+// float32 specialisation: d >= 0, so the bit patterns of squared distances order like the values and
+// (distance, original index) packs into ONE unsigned 64-bit key -- "closer, ties to the smaller
+// index" becomes a single 64-bit compare instead of three compares and two mask operations.
+template <>
+__device__ __forceinline__ void nn_test<float, float4>(const float4 &p, uint32_t j, float qx, float qy, float qz,
+                                                       float &best, uint32_t &bj, uint32_t &borig) {
+    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+    const float d = dist2_f32(dx, dy, dz);
+    const uint32_t o = pt_orig(p);
+    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | o;
+    const unsigned long long cur = ((unsigned long long)__float_as_uint(best) << 32) | borig;
+    const bool take = key < cur;
     best = take ? d : best; bj = take ? j : bj; borig = take ? o : borig;
 }
 
