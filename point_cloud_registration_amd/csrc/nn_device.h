@@ -121,24 +121,40 @@ __device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restr
         const Real kr = RT::sqrt_rn(bound2) * g.inv_h + (Real)2;
         if (kr < (Real)kmax) kmax = (int)kr;
     }
+    // ---- ring 0 (the query's own cell) and the empty-space shortcut, without a second round trip:
+    // one pair of loads gives the cell's range AND its gap field
     int kstart = k0;
-    if (k0 == 0 && g.cs_mask != 0xffffffffu) {
-        // empty-space skipping: the gap field of the query's own cell says how many rings are empty
-        const size_t own = ((size_t)cz * (size_t)g.ny + (size_t)cy) * (size_t)g.nx + (size_t)cx;
-        kstart = (int)(cs[own] >> PCR_GAP_SHIFT);
-        if (kstart > 0 && g.seed) {
-            const uint32_t j0 = g.seed[own];
-            if (j0 != PCR_NONE) nn_test<Real, PT>(pts[j0], j0, qx, qy, qz, best, bj, borig);
+    if (k0 == 0) {
+        const uint32_t own = ((uint32_t)cz * (uint32_t)g.ny + (uint32_t)cy) * (uint32_t)g.nx + (uint32_t)cx;
+        const uint32_t w0 = cs[own], w1 = cs[own + 1];
+        const int gap = g.cs_mask != 0xffffffffu ? (int)(w0 >> PCR_GAP_SHIFT) : 0;
+        if (gap == 0) {
+            const uint32_t s_ = w0 & g.cs_mask, e_ = w1 & g.cs_mask;
+            if (STATS) { st->rings++; st->rows_loaded++; st->cand += ((e_ - s_ + 3) / 4) * 4; }
+            nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
+            kstart = 1;
+        } else {
+            kstart = gap;                       // rings closer than `gap` are empty
+            if (g.seed) {                       // a real point nearby bounds the search from the start
+                const uint32_t j0 = g.seed[own];
+                if (j0 != PCR_NONE) nn_test<Real, PT>(pts[j0], j0, qx, qy, qz, best, bj, borig);
+            }
         }
     }
-    for (int k = kstart; k <= kmax; ++k) {
-        if (k >= 1) {
+    const uint32_t unx = (uint32_t)g.nx, plane = (uint32_t)g.ny * (uint32_t)g.nx;   // ncells < 2^32
+    for (int k = kstart; k <= kmax; ++k) {                                           // k >= 1 from here on
+        {
             const Real lb = (Real)(k - 1) * g.h + fmin_ - g.slack;
             if (lb > (Real)0 && lb * lb > best) break;
         }
         if (STATS) st->rings++;
         const int zlo = max(cz - k, 0), zhi = min(cz + k, g.nz - 1);
         const int ylo = max(cy - k, 0), yhi = min(cy + k, g.ny - 1);
+        const int xlo = max(cx - k, 0), xhi = min(cx + k, g.nx - 1);
+        const int xa = cx - k, xb = cx + k;
+        const bool xa_in = xa >= 0 && xa < g.nx, xb_in = xb >= 0 && xb < g.nx;
+        Real dxa = fmax((Real)(k - 1) * g.h + fx - g.slack, (Real)0), dxb = fmax((Real)k * g.h - fx - g.slack, (Real)0);
+        dxa *= dxa; dxb *= dxb;
         for (int z = zlo; z <= zhi; ++z) {
             const int dzc = z - cz;
             Real dzm = dzc == 0 ? (Real)0 : (dzc > 0 ? (Real)dzc * g.h - fz : (Real)(-dzc - 1) * g.h + fz);
@@ -146,15 +162,15 @@ __device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restr
             const Real dz2 = dzm * dzm;
             if (dz2 > best) continue;
             const bool zshell = (dzc == k) || (dzc == -k);
-            for (int y = ylo; y <= yhi; ++y) {
+            uint32_t row = (uint32_t)z * plane + (uint32_t)ylo * unx;
+            for (int y = ylo; y <= yhi; ++y, row += unx) {
                 const int dyc = y - cy;
                 Real dym = dyc == 0 ? (Real)0 : (dyc > 0 ? (Real)dyc * g.h - fy : (Real)(-dyc - 1) * g.h + fy);
                 dym = fmax(dym - g.slack, (Real)0);
                 const Real dyz2 = dz2 + dym * dym;
                 if (dyz2 > best) { if (STATS) st->rows_pruned++; continue; }
-                const size_t row = ((size_t)z * (size_t)g.ny + (size_t)y) * (size_t)g.nx;
                 if (zshell || dyc == k || dyc == -k) {
-                    int xl = max(cx - k, 0), xh = min(cx + k, g.nx - 1);
+                    int xl = xlo, xh = xhi;
                     if (best < RT::inf()) {                 // clip the row to the remaining budget
                         // approximate sqrt is fine here: the clip only has to be conservative
                         const Real xr = RT::sqrt_fast(best - dyz2) * (Real)1.000002 + g.slack;
@@ -163,27 +179,20 @@ __device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restr
                         if (b < (Real)xh) xh = (int)RT::floor_(fmax(b, -lim));
                     }
                     if (xl <= xh) {
-                        const uint32_t s_ = cs[row + xl] & g.cs_mask, e_ = cs[row + xh + 1] & g.cs_mask;
+                        const uint32_t s_ = cs[row + (uint32_t)xl] & g.cs_mask, e_ = cs[row + (uint32_t)xh + 1u] & g.cs_mask;
                         if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + 3) / 4) * 4; }
                         nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
                     }
                 } else {                                    // interior row of the ring: its two end cells
-                    const int xa = cx - k, xb = cx + k;
-                    if (xa >= 0 && xa < g.nx) {
-                        const Real dxm = fmax((Real)(k - 1) * g.h + fx - g.slack, (Real)0);
-                        if (dyz2 + dxm * dxm <= best) {
-                            const uint32_t s_ = cs[row + xa] & g.cs_mask, e_ = cs[row + xa + 1] & g.cs_mask;
-                            if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + 3) / 4) * 4; }
-                            nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
-                        }
+                    if (xa_in && dyz2 + dxa <= best) {
+                        const uint32_t s_ = cs[row + (uint32_t)xa] & g.cs_mask, e_ = cs[row + (uint32_t)xa + 1u] & g.cs_mask;
+                        if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + 3) / 4) * 4; }
+                        nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
                     }
-                    if (xb >= 0 && xb < g.nx) {
-                        const Real dxm = fmax((Real)k * g.h - fx - g.slack, (Real)0);
-                        if (dyz2 + dxm * dxm <= best) {
-                            const uint32_t s_ = cs[row + xb] & g.cs_mask, e_ = cs[row + xb + 1] & g.cs_mask;
-                            if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + 3) / 4) * 4; }
-                            nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
-                        }
+                    if (xb_in && dyz2 + dxb <= best) {
+                        const uint32_t s_ = cs[row + (uint32_t)xb] & g.cs_mask, e_ = cs[row + (uint32_t)xb + 1u] & g.cs_mask;
+                        if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + 3) / 4) * 4; }
+                        nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
                     }
                 }
             }
