@@ -106,7 +106,17 @@ def main():
 
     # ---- workload (synthetic; same target on every rank, own scan shard per rank) -------------
     t_setup = time.perf_counter()
-    target = make_cloud(n_target, seed=0)
+    data_tag = "synthetic"
+    pcd = os.environ.get("PCR_B01_PCD", os.path.join(REPO, "data", "B-01.pcd"))
+    if "b01" in args.config and os.path.exists(pcd):          # the real cloud, if it ever is on the box
+        from point_cloud_registration_amd.io import load_pcd
+        target = np.ascontiguousarray(load_pcd(pcd)["xyz"], dtype=np.float32)
+        n_target = target.shape[0]
+        if n_scan > n_target or args.config in ("plane_b01", "icp_b01"):
+            n_scan = n_target
+        data_tag = "B-01.pcd"
+    else:
+        target = make_cloud(n_target, seed=0)
     scan, T_true = perturbed_scan(target, n_scan if n_scan < n_target else None, seed=2 + rank)
     if kind_name in ("icp", "plane"):
         tgt = _capi.Target.points(ctx, target)
@@ -188,7 +198,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "iterations_per_sec": round(args.steps / elapsed, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "accumulate_dtype": "f64", "data": "synthetic",
+            "dtype": "f32", "accumulate_dtype": "f64", "data": data_tag,
             "config": {"workload": args.config, "description": desc, "kind": kind_name,
                        "target_points": int(n_target), "scan_points_per_gpu": int(sc.n),
                        "max_dist": max_dist, "voxel_size": voxel_size, "parallelism": f"scan-shard x{world}",
