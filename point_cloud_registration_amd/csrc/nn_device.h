@@ -98,55 +98,78 @@ __device__ __forceinline__ void nn_scan_range(const PT *__restrict__ pts, uint32
 // Per-lane work counters, compiled in only for pcr_nn_counters (STATS = true).
 struct NNStats { uint32_t rings, rows_loaded, rows_pruned, cand; };
 
-// On return: bj = cell-sorted index of the nearest point (PCR_NONE if nothing closer than
-// sqrt(bound2)), best = its squared distance, borig = its original index.
-template <typename Real, typename PT, bool STATS = false>
-__device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restrict__ pts,
-                                          const uint32_t *__restrict__ cs,
-                                          Real qx, Real qy, Real qz, Real bound2,
-                                          Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr) {
+// ---- the search, in three pieces so that kernels can regroup lanes between them -----------------
+// Per-query geometry relative to the grid.
+template <typename Real>
+struct NNCell {
+    int cx, cy, cz;        // the query's cell (may lie outside the grid)
+    Real fx, fy, fz;       // offsets of the query inside that cell, in [0, h)
+    Real fmin_;            // distance to the nearest face of that cell
+    int k0, kmax;          // first ring that can touch the grid box / last ring worth visiting
+};
+
+template <typename Real>
+__device__ __forceinline__ NNCell<Real> nn_cell(const Geom<Real> &g, Real qx, Real qy, Real qz, Real bound2) {
     typedef RealTraits<Real> RT;
-    best = bound2; bj = PCR_NONE; borig = PCR_NONE;
+    NNCell<Real> c;
     const Real lim = (Real)1.0e9;
     Real rx = (qx - g.ox) * g.inv_h, ry = (qy - g.oy) * g.inv_h, rz = (qz - g.oz) * g.inv_h;
     rx = fmin(fmax(rx, -lim), lim); ry = fmin(fmax(ry, -lim), lim); rz = fmin(fmax(rz, -lim), lim);
-    const int cx = (int)RT::floor_(rx), cy = (int)RT::floor_(ry), cz = (int)RT::floor_(rz);
-    // offsets of the query inside its own cell
-    const Real fx = (qx - g.ox) - (Real)cx * g.h, fy = (qy - g.oy) - (Real)cy * g.h, fz = (qz - g.oz) - (Real)cz * g.h;
-    const Real fmin_ = fmin(fmin(fmin(fx, g.h - fx), fmin(fy, g.h - fy)), fmin(fz, g.h - fz));
-    // rings that can touch the grid box
-    const int k0 = max(max(max(-cx, cx - (g.nx - 1)), max(-cy, cy - (g.ny - 1))), max(max(-cz, cz - (g.nz - 1)), 0));
-    int kmax = max(max(max(cx, g.nx - 1 - cx), max(cy, g.ny - 1 - cy)), max(cz, g.nz - 1 - cz));
+    c.cx = (int)RT::floor_(rx); c.cy = (int)RT::floor_(ry); c.cz = (int)RT::floor_(rz);
+    c.fx = (qx - g.ox) - (Real)c.cx * g.h; c.fy = (qy - g.oy) - (Real)c.cy * g.h; c.fz = (qz - g.oz) - (Real)c.cz * g.h;
+    c.fmin_ = fmin(fmin(fmin(c.fx, g.h - c.fx), fmin(c.fy, g.h - c.fy)), fmin(c.fz, g.h - c.fz));
+    c.k0 = max(max(max(-c.cx, c.cx - (g.nx - 1)), max(-c.cy, c.cy - (g.ny - 1))), max(max(-c.cz, c.cz - (g.nz - 1)), 0));
+    c.kmax = max(max(max(c.cx, g.nx - 1 - c.cx), max(c.cy, g.ny - 1 - c.cy)), max(c.cz, g.nz - 1 - c.cz));
     if (bound2 < RT::inf()) {
         const Real kr = RT::sqrt_rn(bound2) * g.inv_h + (Real)2;
-        if (kr < (Real)kmax) kmax = (int)kr;
+        if (kr < (Real)c.kmax) c.kmax = (int)kr;
     }
-    // ---- ring 0 (the query's own cell) and the empty-space shortcut, without a second round trip:
-    // one pair of loads gives the cell's range AND its gap field
-    int kstart = k0;
-    if (k0 == 0) {
-        const uint32_t own = ((uint32_t)cz * (uint32_t)g.ny + (uint32_t)cy) * (uint32_t)g.nx + (uint32_t)cx;
-        const uint32_t w0 = cs[own], w1 = cs[own + 1];
-        const int gap = g.cs_mask != 0xffffffffu ? (int)(w0 >> PCR_GAP_SHIFT) : 0;
-        if (gap == 0) {
-            const uint32_t s_ = w0 & g.cs_mask, e_ = w1 & g.cs_mask;
-            if (STATS) { st->rings++; st->rows_loaded++; st->cand += ((e_ - s_ + 3) / 4) * 4; }
-            nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
-            kstart = 1;
-        } else {
-            kstart = gap;                       // rings closer than `gap` are empty
-            if (g.seed) {                       // a real point nearby bounds the search from the start
-                const uint32_t j0 = g.seed[own];
-                if (j0 != PCR_NONE) nn_test<Real, PT>(pts[j0], j0, qx, qy, qz, best, bj, borig);
-            }
-        }
+    return c;
+}
+
+// Ring 0 (the query's own cell) and the empty-space shortcut, from ONE pair of loads (the cell's
+// range and its gap field).  Returns the first ring that still has to be visited (>= 1).
+template <typename Real, typename PT, bool STATS = false>
+__device__ __forceinline__ int nn_ring0(const Geom<Real> &g, const PT *__restrict__ pts, const uint32_t *__restrict__ cs,
+                                        const NNCell<Real> &c, Real qx, Real qy, Real qz,
+                                        Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr) {
+    if (c.k0 != 0) return c.k0;                   // outside the grid box: rings below k0 hold no cells
+    const uint32_t own = ((uint32_t)c.cz * (uint32_t)g.ny + (uint32_t)c.cy) * (uint32_t)g.nx + (uint32_t)c.cx;
+    const uint32_t w0 = cs[own], w1 = cs[own + 1];
+    const int gap = g.cs_mask != 0xffffffffu ? (int)(w0 >> PCR_GAP_SHIFT) : 0;
+    if (gap == 0) {
+        const uint32_t s_ = w0 & g.cs_mask, e_ = w1 & g.cs_mask;
+        if (STATS) { st->rings++; st->rows_loaded++; st->cand += ((e_ - s_ + 3) / 4) * 4; }
+        nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
+        return 1;
     }
+    if (g.seed) {                                 // a real point nearby bounds the search from the start
+        const uint32_t j0 = g.seed[own];
+        if (j0 != PCR_NONE) nn_test<Real, PT>(pts[j0], j0, qx, qy, qz, best, bj, borig);
+    }
+    return gap;                                   // rings closer than `gap` are empty
+}
+
+// true when ring `k` (>= 1) and everything beyond it cannot improve on `best`
+template <typename Real>
+__device__ __forceinline__ bool nn_certified(const Geom<Real> &g, const NNCell<Real> &c, int k, Real best) {
+    if (k > c.kmax) return true;
+    const Real lb = (Real)(k - 1) * g.h + c.fmin_ - g.slack;
+    return lb > (Real)0 && lb * lb > best;
+}
+
+// Rings kstart (>= 1) .. kmax.
+template <typename Real, typename PT, bool STATS = false>
+__device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restrict__ pts, const uint32_t *__restrict__ cs,
+                                         const NNCell<Real> &c, int kstart, Real qx, Real qy, Real qz,
+                                         Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr) {
+    typedef RealTraits<Real> RT;
+    const Real lim = (Real)1.0e9;
+    const int cx = c.cx, cy = c.cy, cz = c.cz;
+    const Real fx = c.fx, fy = c.fy, fz = c.fz;
     const uint32_t unx = (uint32_t)g.nx, plane = (uint32_t)g.ny * (uint32_t)g.nx;   // ncells < 2^32
-    for (int k = kstart; k <= kmax; ++k) {                                           // k >= 1 from here on
-        {
-            const Real lb = (Real)(k - 1) * g.h + fmin_ - g.slack;
-            if (lb > (Real)0 && lb * lb > best) break;
-        }
+    for (int k = kstart; k <= c.kmax; ++k) {
+        if (nn_certified<Real>(g, c, k, best)) break;
         if (STATS) st->rings++;
         const int zlo = max(cz - k, 0), zhi = min(cz + k, g.nz - 1);
         const int ylo = max(cy - k, 0), yhi = min(cy + k, g.ny - 1);
@@ -198,4 +221,17 @@ __device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restr
             }
         }
     }
+}
+
+// On return: bj = cell-sorted index of the nearest point (PCR_NONE if nothing closer than
+// sqrt(bound2)), best = its squared distance, borig = its original index.
+template <typename Real, typename PT, bool STATS = false>
+__device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restrict__ pts,
+                                          const uint32_t *__restrict__ cs,
+                                          Real qx, Real qy, Real qz, Real bound2,
+                                          Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr) {
+    best = bound2; bj = PCR_NONE; borig = PCR_NONE;
+    const NNCell<Real> c = nn_cell<Real>(g, qx, qy, qz, bound2);
+    const int kstart = nn_ring0<Real, PT, STATS>(g, pts, cs, c, qx, qy, qz, best, bj, borig, st);
+    nn_rings<Real, PT, STATS>(g, pts, cs, c, kstart, qx, qy, qz, best, bj, borig, st);
 }
