@@ -70,15 +70,15 @@ class _CentroidTree:
         return self._target.nn_query(np.asarray(points))
 
 
-def voxel_filter(points, voxel_size):
+def voxel_filter(points, voxel_size, device=None):
     """Voxel-grid down-sampling: one centroid per occupied voxel, ascending key order
-    (voxel.py:209-241)."""
-    points = np.asarray(points)
-    keys = get_keys(points, voxel_size)
-    _, inv = np.unique(keys, return_inverse=True)
-    counts = np.bincount(inv).astype(np.float64)
-    out = np.stack([np.bincount(inv, weights=points[:, a]) / counts for a in range(3)], axis=1)
-    return out.astype(np.float32)
+    (voxel.py:209-241).  Runs on the GPU through the voxel build (hash, radix sort, per-voxel
+    float64 mean) with ``min_points=1``; the result is cast to float32 as in the reference."""
+    t = _capi.Target.voxels(_capi.get_context(device), np.asarray(points), voxel_size, 1)
+    try:
+        return t.voxel_stats(("mean",))["mean"].astype(np.float32)
+    finally:
+        t.close()
 
 
 def color_by_voxel(points, voxel_size):

@@ -138,10 +138,6 @@ def test_voxel_host_utilities(g3):
     pts = g3["points_f32"]
     for vs in (0.5, 1.0):
         assert np.array_equal(pcr.get_keys(pts, vs), g3[f"f32_vs{vs}_keys"])
-    f = pcr.voxel_filter(pts, 0.5)
-    uniq, inv = np.unique(g3["f32_vs0.5_keys"], return_inverse=True)
-    assert f.shape == (len(uniq), 3) and f.dtype == np.float32
-    assert np.allclose(f[inv[0]], pts[inv == inv[0]].astype(np.float64).mean(0), atol=1e-6)
     c = pcr.color_by_voxel(pts, 0.5)
     assert c["xyz"].shape == pts.shape and c["irgb"].dtype == np.uint32
     lines = pcr.get_norm_lines(pts[:5], np.tile([0, 0, 1.0], (5, 1)).astype(np.float32), 0.1)
