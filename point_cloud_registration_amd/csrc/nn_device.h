@@ -76,22 +76,25 @@ __device__ __forceinline__ void nn_test<float, float4>(const float4 &p, uint32_t
 }
 
 // The search is latency-bound (one L2 round trip per dependent load, ~500 cycles): candidates are
-// fetched four at a time so four loads are in flight per lane before the first compare.  A batch
-// may run up to 3 records past the end of the range: those are real points of the following cells
+// fetched PCR_NN_BATCH at a time so that many loads are in flight per lane before the first compare.
+// A batch may run up to PCR_NN_BATCH-1 records past the end of the range: those are real points of the following cells
 // (testing an extra true candidate can only help), and the array carries PCR_PTS_PAD sentinel
 // records at +inf behind its last point, which never win a comparison.
-#define PCR_PTS_PAD 4
+#define PCR_PTS_PAD 8
+#ifndef PCR_NN_BATCH
+#define PCR_NN_BATCH 4   // measured: 8 costs occupancy (101 VGPR) and is slower except for tiny scans
+#endif
 template <typename Real, typename PT>
 __device__ __forceinline__ void nn_scan_range(const PT *__restrict__ pts, uint32_t s, uint32_t e,
                                               Real qx, Real qy, Real qz,
                                               Real &best, uint32_t &bj, uint32_t &borig) {
-    for (uint32_t j = s; j < e; j += 4) {
+    for (uint32_t j = s; j < e; j += PCR_NN_BATCH) {
         const PT *__restrict__ b = pts + j;
-        const PT p0 = b[0], p1 = b[1], p2 = b[2], p3 = b[3];
-        nn_test<Real, PT>(p0, j, qx, qy, qz, best, bj, borig);
-        nn_test<Real, PT>(p1, j + 1, qx, qy, qz, best, bj, borig);
-        nn_test<Real, PT>(p2, j + 2, qx, qy, qz, best, bj, borig);
-        nn_test<Real, PT>(p3, j + 3, qx, qy, qz, best, bj, borig);
+        PT p[PCR_NN_BATCH];
+#pragma unroll
+        for (int u = 0; u < PCR_NN_BATCH; ++u) p[u] = b[u];
+#pragma unroll
+        for (int u = 0; u < PCR_NN_BATCH; ++u) nn_test<Real, PT>(p[u], j + u, qx, qy, qz, best, bj, borig);
     }
 }
 
@@ -139,7 +142,7 @@ __device__ __forceinline__ int nn_ring0(const Geom<Real> &g, const PT *__restric
     const int gap = g.cs_mask != 0xffffffffu ? (int)(w0 >> PCR_GAP_SHIFT) : 0;
     if (gap == 0) {
         const uint32_t s_ = w0 & g.cs_mask, e_ = w1 & g.cs_mask;
-        if (STATS) { st->rings++; st->rows_loaded++; st->cand += ((e_ - s_ + 3) / 4) * 4; }
+        if (STATS) { st->rings++; st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
         nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
         return 1;
     }
@@ -203,18 +206,18 @@ __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restri
                     }
                     if (xl <= xh) {
                         const uint32_t s_ = cs[row + (uint32_t)xl] & g.cs_mask, e_ = cs[row + (uint32_t)xh + 1u] & g.cs_mask;
-                        if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + 3) / 4) * 4; }
+                        if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
                         nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
                     }
                 } else {                                    // interior row of the ring: its two end cells
                     if (xa_in && dyz2 + dxa <= best) {
                         const uint32_t s_ = cs[row + (uint32_t)xa] & g.cs_mask, e_ = cs[row + (uint32_t)xa + 1u] & g.cs_mask;
-                        if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + 3) / 4) * 4; }
+                        if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
                         nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
                     }
                     if (xb_in && dyz2 + dxb <= best) {
                         const uint32_t s_ = cs[row + (uint32_t)xb] & g.cs_mask, e_ = cs[row + (uint32_t)xb + 1u] & g.cs_mask;
-                        if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + 3) / 4) * 4; }
+                        if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
                         nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
                     }
                 }
