@@ -4,6 +4,7 @@ import numpy as np
 
 from . import _capi
 from .kdtree import KDTree
+from .math_tools import skew, transform_points
 from .registration import Registration
 
 
@@ -21,3 +22,20 @@ class ICP(Registration):
         self.target = target
         self._target = self.kdtree._target        # the registration kernels share the tree's index
         self._is_target_set = True
+
+    def calc_H_g_e2_no_parallel_ver(self, cur_T, source):
+        """Per-point loop of the same sums, for reading and for tests (the reference keeps one too,
+        icp.py:59-90).  Host Python over the GPU's correspondences; uses the consistent gradient
+        J^T r, so it equals ``calc_H_g_e2`` at R = I and differs at R != I by quirk Q1."""
+        cur_T = np.asarray(cur_T, dtype=np.float64)
+        R = cur_T[:3, :3]
+        src_trans = transform_points(cur_T.astype(np.float32), np.asarray(source, dtype=np.float32))
+        dist, idx = self.kdtree.query(src_trans)
+        H, g, e2 = np.zeros((6, 6)), np.zeros(6), 0.0
+        for i in np.nonzero(dist < self.max_dist)[0]:
+            J = np.hstack([np.eye(3), -R @ skew(np.asarray(source[i], dtype=np.float64))])
+            r = (src_trans[i] - self.target[idx[i]]).astype(np.float64)
+            H += J.T @ J
+            g += J.T @ r
+            e2 += r @ r
+        return H, g, e2

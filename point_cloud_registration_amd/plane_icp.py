@@ -4,6 +4,7 @@ import numpy as np
 
 from . import _capi
 from .kdtree import KDTree
+from .math_tools import skew, transform_points
 from .registration import Registration
 
 
@@ -38,3 +39,24 @@ class PlaneICP(Registration):
             self.kdtree._target.set_normals(self.normal)
         self._target = self.kdtree._target
         self._is_target_set = True
+
+    def calc_H_g_e2_no_parallel_ver(self, cur_T, source):
+        """Per-point loop of the same sums (the reference keeps one, plane_icp.py:72-101); host Python
+        over the GPU's correspondences, gate on the point distance as in the vectorised path."""
+        return _plane_loop(cur_T, source, self.kdtree.query, self.target, self.normal, self.max_dist)
+
+
+def _plane_loop(cur_T, source, query, means, norms, max_dist):
+    cur_T = np.asarray(cur_T, dtype=np.float64)
+    R = cur_T[:3, :3]
+    src_trans = transform_points(cur_T.astype(np.float32), np.asarray(source, dtype=np.float32))
+    dist, idx = query(src_trans)
+    H, g, e2 = np.zeros((6, 6)), np.zeros(6), 0.0
+    for i in np.nonzero(dist < max_dist)[0]:
+        n = np.asarray(norms[idx[i]], dtype=np.float64)
+        r = float(n @ (src_trans[i] - means[idx[i]]))
+        J = np.concatenate([n, skew(np.asarray(source[i], dtype=np.float64)) @ (R.T @ n)])
+        H += np.outer(J, J)
+        g += J * r
+        e2 += r * r
+    return H, g, e2

@@ -18,3 +18,9 @@ class VPlaneICP(Registration):
         self.voxels.set_points(target)
         self._target = self.voxels._target
         self._is_target_set = True
+
+    def calc_H_g_e2_no_parallel_ver(self, cur_T, source):
+        """Per-point loop of the same sums (voxelized_plane_icp.py:67-101): nearest voxel centroid and
+        voxel normal, gate on the centroid distance."""
+        from .plane_icp import _plane_loop
+        return _plane_loop(cur_T, source, self.voxels.kdtree.query, self.voxels.mean, self.voxels.norm, self.max_dist)
