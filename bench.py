@@ -240,8 +240,11 @@ def cpu_baseline(kind_name, target, scan, gpu_target, traj, max_dist, voxel_size
     kind = {"icp": orc.ICP, "plane": orc.PLANE, "vplane": orc.VPLANE, "ndt": orc.NDT}[kind_name]
     orc.calc_H_g_e2(kind, ot, traj[0], src[:10000], max_dist)            # warm-up
     t0 = time.perf_counter()
-    for k in range(passes):
-        orc.calc_H_g_e2(kind, ot, traj[k % len(traj)], src, max_dist)
+    done = 0
+    while done < passes or (time.perf_counter() - t0 < 10.0 and done < 200):     # ~10 s of CPU work
+        orc.calc_H_g_e2(kind, ot, traj[done % len(traj)], src, max_dist)
+        done += 1
+    passes = done
     dt = time.perf_counter() - t0
     return {"value": round(src.shape[0] * passes / dt / 1e6, 4), "unit": "Mcorr/s",
             "cores": orc.max_threads(), "host_cpus": os.cpu_count(), "kind": "port",
