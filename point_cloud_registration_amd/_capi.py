@@ -4,8 +4,10 @@ There is NO CPU fallback: if the HIP library is missing or no MI355X is visible,
 raise.  (The CPU restatement under oracle/ is test infrastructure and is never imported here.)
 """
 
+import atexit
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -21,6 +23,9 @@ K_LINEARIZE, K_FINALIZE, K_NN, K_REDUCE, K_ALLREDUCE, K_COUNT = 0, 1, 2, 3, 4, 5
 KERNEL_NAMES = ("linearize", "finalize", "nn", "reduce", "allreduce")
 
 _lib = None
+_torch_lib_dir = None           # set when torch's bundled HIP runtime was pre-loaded (see below)
+_live = weakref.WeakSet()      # targets / scans still holding device memory
+_shutdown = False
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -72,6 +77,46 @@ class PcrError(RuntimeError):
     """HIP / RCCL / argument failure reported by libpcr_hip.so."""
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  A PyTorch-ROCm wheel bundles its own libamdhip64.so and loads it
+    by path; if libpcr_hip.so has already pulled in /opt/rocm's copy, a later ``import torch`` leaves
+    TWO runtimes in the process (observed: "double free or corruption" at exit).  When torch is
+    installed but not imported yet, load its runtime first so both sides resolve to the same one
+    (same SONAME, libamdhip64.so.7).  PCR_KEEP_SYSTEM_HIP=1 skips this."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("PCR_KEEP_SYSTEM_HIP"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    global _torch_lib_dir
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    path = os.path.join(libdir, "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+            _torch_lib_dir = libdir
+        except OSError:
+            pass
+
+
+def _share_rccl_with_torch():
+    """Same idea for RCCL (bound lazily with dlopen("librccl.so.1") inside libpcr_hip.so): when the
+    process runs on torch's HIP runtime, use the RCCL built against it."""
+    if _torch_lib_dir is None:
+        return
+    path = os.path.join(_torch_lib_dir, "librccl.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load libpcr_hip.so (built in-tree by __graft_entry__.build() / csrc/Makefile)."""
     global _lib
@@ -81,6 +126,7 @@ def lib():
         raise PcrError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the registration hot path.")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(L, name)          # AttributeError if the symbol is not exported
@@ -132,6 +178,7 @@ class Context:
 
     # -- RCCL
     def comm_init(self, uid, nranks, rank):
+        _share_rccl_with_torch()
         check(lib().pcr_comm_init(self.handle, uid, int(nranks), int(rank)))
         self.nranks, self.rank = int(nranks), int(rank)
 
@@ -153,13 +200,34 @@ class Context:
         return {KERNEL_NAMES[i]: (int(n[i]), float(ms[i])) for i in range(K_COUNT)}
 
     def close(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and not _shutdown:
             lib().pcr_context_destroy(self.handle)
-            self.handle = None
+        self.handle = None
+
+
+@atexit.register
+def _release_all():
+    """Free every device object and context while the HIP runtime is still alive.  Leaving this to
+    ``__del__`` during interpreter teardown runs hipFree after the runtime's own static destructors
+    (observed: "double free or corruption" at exit of a long pytest run)."""
+    global _shutdown
+    for obj in list(_live):
+        try:
+            obj.close()
+        except Exception:
+            pass
+    for ctx in list(_contexts.values()):
+        try:
+            ctx.close()
+        except Exception:
+            pass
+    _contexts.clear()
+    _shutdown = True
 
 
 def comm_unique_id():
     buf = C.create_string_buffer(128)
+    _share_rccl_with_torch()
     check(lib().pcr_comm_unique_id(buf))
     return buf.raw
 
@@ -188,6 +256,7 @@ class Target:
 
     def __init__(self, ctx, handle, is_voxel):
         self.ctx, self.handle, self.is_voxel = ctx, handle, is_voxel
+        _live.add(self)
 
     @classmethod
     def points(cls, ctx, xyz, normals=None, cell_hint=0.0):
@@ -283,9 +352,9 @@ class Target:
         return dist, idx
 
     def close(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and not _shutdown:
             lib().pcr_target_destroy(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __del__(self):
         try:
@@ -310,11 +379,12 @@ class Scan:
             check(lib().pcr_scan_create(ctx.handle, _ptr(xyz), xyz.shape[0], int(flags), C.byref(h)))
             self.n = xyz.shape[0]
         self.handle = h
+        _live.add(self)
 
     def close(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and not _shutdown:
             lib().pcr_scan_destroy(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __del__(self):
         try:

@@ -46,7 +46,7 @@ def _worker(rank, world, port, q):
 
 
 def test_two_ranks_one_gpu_sharded_plane_icp(g2):
-    import torch.multiprocessing as mp
+    import multiprocessing as mp            # (not torch.multiprocessing: keep torch out of the parent)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
