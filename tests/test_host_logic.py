@@ -22,7 +22,7 @@ class _OracleBacked:
     """Mixin: replaces the two GPU touch points of Registration with the CPU oracle so the HOST
     logic (align loop, quirks Q3/Q4/Q7, solve, plus) can be exercised without a GPU."""
 
-    def _scan_for(self, source):
+    def _scan_for(self, source, fresh=False):
         return np.ascontiguousarray(source, dtype=np.float32)
 
     def _linearize(self, cur_T, scan):
