@@ -380,3 +380,55 @@ def test_robustness_edge_inputs(capi, orc, ctx):
     st = tv.voxel_stats(("cov", "icov", "norm"))
     assert tv.size() == 1 and np.isfinite(st["icov"]).all() and np.isfinite(st["norm"]).all()
     assert np.allclose(st["icov"], orc.calc_icov(st["cov"]), rtol=1e-12, atol=0)
+
+
+# ----------------------------------------------------------------------------- remaining API surface
+def test_device_pointer_entry_points(capi, ctx, g2):
+    """pcr_target_points_create_device / pcr_scan_create_device with device memory owned by the
+    caller (a torch tensor): same sums as the host-pointer path, and torch shares our HIP runtime."""
+    import torch
+    assert torch.cuda.is_available()
+    tgt_host = capi.Target.points(ctx, g2["target"], g2["plane_normals"])
+    a = capi.linearize(tgt_host, capi.Scan(ctx, g2["source"]), capi.PLANE, g2["T"], 0.8)
+    d_t = torch.from_numpy(np.ascontiguousarray(g2["target"], np.float32)).cuda()
+    d_n = torch.from_numpy(np.ascontiguousarray(g2["plane_normals"], np.float32)).cuda()
+    d_s = torch.from_numpy(np.ascontiguousarray(g2["source"], np.float32)).cuda()
+    torch.cuda.synchronize()
+    tgt_dev = capi.Target.points_device(ctx, d_t.data_ptr(), d_t.shape[0], d_n.data_ptr())
+    scan_dev = capi.Scan(ctx, device_ptr=d_s.data_ptr(), n=d_s.shape[0])
+    b = capi.linearize(tgt_dev, scan_dev, capi.PLANE, g2["T"], 0.8)
+    assert np.array_equal(a, b)
+    import os
+    maps = open(f"/proc/{os.getpid()}/maps").read()
+    assert len({l.split()[-1] for l in maps.splitlines() if "libamdhip64" in l}) == 1     # one runtime
+
+
+def test_class_level_helpers(capi, orc, g2, g6, capsys):
+    import point_cloud_registration_amd as pcr
+    # VoxelGrid.query: nearest kept voxel's statistics + 'dist' (voxel.py:171-179)
+    vg = pcr.VoxelGrid(float(g2["voxel_size"]))
+    vg.set_points(g2["target"])
+    vg.calc_icov()
+    st = orc.transform(g2["T"], g2["source"])
+    q = vg.query(st, ["mean", "norm", "icov"])
+    ov = orc.TargetVoxels(g2["target"], float(g2["voxel_size"]))
+    do, io = orc.nn_brute_f64(ov.mean, st)
+    assert np.array_equal(q["dist"], do) and np.array_equal(q["mean"], ov.mean[io])
+    assert np.allclose(q["icov"], ov.icov[io], rtol=1e-12, atol=0) and q["norm"].shape == (len(st), 3)
+    vg.calc_sqrt_icov()
+    assert vg.sqrt_icov.shape == vg.icov.shape
+    # KDTree.query with an upper bound; estimate_normals at top level
+    tree = pcr.KDTree(g2["target"])
+    d, i = tree.query(st, distance_upper_bound=0.5)
+    dn, inn = orc.nn_brute(g2["target"], st)
+    far = ~(dn < 0.5)
+    assert np.all(i[far] == -1) and np.all(np.isinf(d[far])) and np.array_equal(i[~far], inn[~far])
+    n = pcr.estimate_normals(g6["points"], k=15)
+    assert n.shape == g6["points"].shape and n.dtype == np.float32
+    assert np.mean(np.abs(np.sum(n * g6["normals_k15"], axis=1)) > 0.999) > 0.9
+    # verbose align prints the reference's line format (registration.py:91-92)
+    icp = pcr.ICP(max_dist=float(g2["max_dist"]))
+    icp.set_target(g2["target"])
+    icp.align(g2["source"], np.eye(4), verbose=True)
+    out = capsys.readouterr().out.splitlines()
+    assert out[0].startswith("iter 0, error ") and len(out) == icp.last_iterations
