@@ -400,6 +400,15 @@ __global__ void __launch_bounds__(1024) k_finalize(const FinArgs f) {
     }
 }
 
+// after the RCCL all-reduce: hand the 29 doubles to the host the same zero-copy way k_finalize does
+__global__ void __launch_bounds__(64) k_publish(const double *__restrict__ out, double *host_out,
+                                                volatile uint32_t *host_flag, uint32_t seq) {
+    if (threadIdx.x < 29) host_out[threadIdx.x] = out[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) *host_flag = seq;
+}
+
 // ---- fine seam: plain NN queries (no transform), original indices out -------------------------
 template <typename Real, typename PT>
 __global__ void __launch_bounds__(256) k_nn_query(Geom<Real> g, const PT *pts, const uint32_t *cs,
@@ -544,13 +553,20 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
     pcr_prof_end(ctx, &ev);
     HIP_TRY(hipGetLastError());
 
+    bool flagged = direct;
     if (ctx->comm) {
         pcr_prof_begin(ctx, PCR_K_ALLREDUCE, &ev);
         pcr_status cs = pcr_comm_allreduce29(ctx, ctx->d_out);
+        if (cs == PCR_OK && ctx->h_out_dev) {
+            hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, ctx->d_out, ctx->h_out_dev,
+                               (volatile uint32_t *)(ctx->h_out_dev + 32), f.seq);
+            flagged = true;
+        }
         pcr_prof_end(ctx, &ev);
         if (cs != PCR_OK) return cs;
+        HIP_TRY(hipGetLastError());
     }
-    if (direct) {
+    if (flagged) {
         bool seen = false;
         for (long spin = 0; spin < 4000000L; ++spin) {
             if (*flag == f.seq) { seen = true; break; }
