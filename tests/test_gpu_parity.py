@@ -432,3 +432,39 @@ def test_class_level_helpers(capi, orc, g2, g6, capsys):
     icp.align(g2["source"], np.eye(4), verbose=True)
     out = capsys.readouterr().out.splitlines()
     assert out[0].startswith("iter 0, error ") and len(out) == icp.last_iterations
+
+
+def test_nn_stress_cell_boundaries(capi, orc, ctx):
+    """Exactness where the pruning bounds are tightest: points and queries ON cell boundaries (lattice
+    coordinates that are exact multiples of the cell size), clustered / planar / collinear clouds,
+    cell sizes from much smaller to much larger than the point spacing, bounded and unbounded."""
+    rng = np.random.default_rng(123)
+    for trial in range(12):
+        kind = trial % 4
+        n = int(rng.integers(200, 4000))
+        if kind == 0:                                       # integer lattice, heavy ties
+            tgt = rng.integers(-8, 9, (n, 3)).astype(np.float32) * np.float32(0.25)
+        elif kind == 1:                                     # thin plane + clusters
+            tgt = rng.normal(0, 1, (n, 3)).astype(np.float32); tgt[:, 2] *= np.float32(0.01)
+            tgt[: n // 4] = tgt[: n // 4] * np.float32(0.05) + np.float32([3, 3, 0])
+        elif kind == 2:                                     # a line along an axis-diagonal
+            s = rng.uniform(-5, 5, n).astype(np.float32); tgt = np.stack([s, s, -s], 1)
+        else:                                               # uniform volume with a far outlier
+            tgt = rng.uniform(-2, 2, (n, 3)).astype(np.float32); tgt[0] = [40, -35, 20]
+        cell = float(rng.choice([0.03, 0.1, 0.25, 0.5, 1.0, 4.0]))
+        q = np.vstack([rng.uniform(-6, 6, (600, 3)),
+                       rng.integers(-10, 11, (300, 3)) * cell,            # queries exactly on cell faces / corners
+                       tgt[rng.integers(0, n, 200)].astype(np.float64)]).astype(np.float32)
+        t = capi.Target.points(ctx, tgt, cell_hint=cell)
+        d, i = t.nn_query(q)
+        do, io = orc.nn_brute(tgt, q)
+        assert np.array_equal(i, io), (trial, kind, cell)
+        assert np.array_equal(d, do), (trial, kind, cell)
+        r = float(rng.choice([0.2, 1.0, 3.0]))
+        db, ib = t.nn_query(q, r_max=r)
+        keep = do < r
+        assert np.array_equal(ib[keep], io[keep]) and np.all(ib[~keep] == -1), (trial, kind, cell, r)
+        dk, ik = t.knn_query(q[:200], 7)
+        dko, iko = orc.knn_brute(tgt, q[:200], 7)
+        assert np.array_equal(ik, iko) and np.array_equal(dk, dko), (trial, kind, cell)
+        t.close()
