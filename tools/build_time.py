@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""set_target-side timings (index build, normals, voxel build) at several sizes."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from point_cloud_registration_amd import _capi
+from point_cloud_registration_amd.synthetic import street, street_tiled
+ctx = _capi.get_context(0)
+_capi.Target.points(ctx, street(10000)).close()
+for n in [int(float(a)) for a in (sys.argv[1:] or ["1.06e6", "1e7"])]:
+    pts = street(n) if n <= 2_000_000 else street_tiled(n)
+    t0 = time.perf_counter(); t = _capi.Target.points(ctx, pts); ctx.synchronize(); t1 = time.perf_counter()
+    t.estimate_normals(15, want=False); ctx.synchronize(); t2 = time.perf_counter()
+    info = t.index_info(); t.close()
+    t3 = time.perf_counter(); v = _capi.Target.voxels(ctx, pts, 1.0, 10); ctx.synchronize(); t4 = time.perf_counter()
+    nv = v.size(); v.close()
+    sc0 = time.perf_counter(); s = _capi.Scan(ctx, pts[: min(n, 12_500_000)]); ctx.synchronize(); sc1 = time.perf_counter(); s.close()
+    print(f"n={n}: point index {t1 - t0:.3f} s (cell {info['cell']:.3f}, dims {info['dims']}), normals k=15 {t2 - t1:.3f} s, "
+          f"voxel build {t4 - t3:.3f} s ({nv} voxels), scan upload+sort {sc1 - sc0:.3f} s", flush=True)
