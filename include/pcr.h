@@ -167,8 +167,9 @@ PCR_API pcr_status pcr_profile_read(pcr_context *ctx, int64_t launches[PCR_K_COU
 PCR_API pcr_status pcr_target_index_info(pcr_target *t, double *cell, int64_t dims[3], int64_t *occupied, int64_t *n);
 /* work counters of the NN search for one pose (point targets): out[0..3] = rings entered, row
  * segments loaded, rows pruned by arithmetic, candidates tested, summed over queries; out[4..7] = the
- * same with each wave's maximum charged to all 64 lanes (the cost under divergence)                */
-PCR_API pcr_status pcr_nn_counters(pcr_target *t, pcr_scan *s, const double T[16], double max_dist, double out[8]);
+ * same with each wave's maximum charged to all 64 lanes (the cost under divergence); out[8..10] =
+ * wave wall-clock cycles summed over waves: prologue (load, transform, cell), ring 0, outer rings   */
+PCR_API pcr_status pcr_nn_counters(pcr_target *t, pcr_scan *s, const double T[16], double max_dist, double out[11]);
 /* select the hot-path variant: 0 = fused transform+NN+reduce kernel (default), 1 = NN kernel
  * writing correspondences to HBM followed by a reduce kernel                               */
 PCR_API pcr_status pcr_set_variant(pcr_context *ctx, int variant);

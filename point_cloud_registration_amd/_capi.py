@@ -417,13 +417,15 @@ def align(target, scan, kind, T_init, max_iter, tol, max_dist, flags=FLAG_ICP_RR
 
 def nn_counters(target, scan, T, max_dist):
     """Search work counters for one pose (see include/pcr.h: pcr_nn_counters)."""
-    out = np.zeros(8)
+    out = np.zeros(11)
     check(lib().pcr_nn_counters(target.handle, scan.handle, np.ascontiguousarray(T, np.float64).reshape(16),
                                 float(max_dist), out))
     names = ("rings", "rows_loaded", "rows_pruned", "candidates")
     n = max(scan.n, 1)
+    waves = max((scan.n + 63) // 64, 1)
     return {**{k: out[i] / n for i, k in enumerate(names)},
-            **{"wave_" + k: out[4 + i] / n for i, k in enumerate(names)}}
+            **{"wave_" + k: out[4 + i] / n for i, k in enumerate(names)},
+            "cyc_prologue": out[8] / waves, "cyc_ring0": out[9] / waves, "cyc_rings": out[10] / waves}
 
 
 def unpack29(out):

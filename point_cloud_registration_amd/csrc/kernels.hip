@@ -292,26 +292,40 @@ __global__ void __launch_bounds__(256) k_nn_scan(const LinArgs a) {
 __global__ void __launch_bounds__(256) k_nn_counters(const LinArgs a, unsigned long long *out) {
     const TileIter it(a);
     unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long cyc[3] = {0, 0, 0};                  // wave wall-clock: prologue, ring 0, outer rings
     for (int64_t i0 = it.base - threadIdx.x; i0 < it.end; i0 += it.stride) {
         const int64_t i = i0 + threadIdx.x;
         NNStats st = {0, 0, 0, 0};
-        if (i < it.end) {
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        float tx = 0, ty = 0, tz = 0;
+        const bool live = i < it.end;
+        if (live) {
             const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
-            float tx, ty, tz;
             xform(a, x, y, z, tx, ty, tz);
-            uint32_t bj, bo; float best;
-            nn_search<float, PtF, true>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo, &st);
         }
+        uint32_t bj = PCR_NONE, bo = PCR_NONE; float best = a.bound2_f;
+        NNCell<float> c = nn_cell<float>(a.gf, tx, ty, tz, a.bound2_f);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long t1 = __builtin_readcyclecounter();
+        int kstart = 0;
+        if (live) kstart = nn_ring0<float, PtF, true>(a.gf, a.pts, a.cell_start, c, tx, ty, tz, best, bj, bo, &st);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long t2 = __builtin_readcyclecounter();
+        if (live) nn_rings<float, PtF, true>(a.gf, a.pts, a.cell_start, c, kstart, tx, ty, tz, best, bj, bo, &st);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long t3 = __builtin_readcyclecounter();
+        cyc[0] += t1 - t0; cyc[1] += t2 - t1; cyc[2] += t3 - t2;
         uint32_t v[4] = {st.rings, st.rows_loaded, st.rows_pruned, st.cand};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            uint32_t m = v[c];
+        for (int c4 = 0; c4 < 4; ++c4) {
+            uint32_t m = v[c4];
             for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
-            acc[c] += v[c];
-            acc[4 + c] += m;
+            acc[c4] += v[c4];
+            acc[4 + c4] += m;
         }
     }
     for (int c = 0; c < 8; ++c) atomicAdd(&out[c], acc[c]);
+    if ((threadIdx.x & 63) == 0) for (int c = 0; c < 3; ++c) atomicAdd(&out[8 + c], cyc[c]);
 }
 
 template <int KIND>
@@ -625,7 +639,7 @@ pcr_status pcr_run_nn(pcr_target *t, const float *d_q, int64_t m, double r_max, 
 }
 
 // ---- instrumentation: search work counters for one pose (point targets) ------------------------
-extern "C" pcr_status pcr_nn_counters(pcr_target *t, pcr_scan *s, const double T[16], double max_dist, double out[8]) {
+extern "C" pcr_status pcr_nn_counters(pcr_target *t, pcr_scan *s, const double T[16], double max_dist, double out[11]) {
     PCR_REQUIRE(t && s && T && out, "NULL argument");
     PCR_REQUIRE(!t->is_voxel, "counters are implemented for point targets");
     pcr_context *ctx = t->ctx;
@@ -642,7 +656,7 @@ extern "C" pcr_status pcr_nn_counters(pcr_target *t, pcr_scan *s, const double T
     const double bound = max_dist * (1.0 + 1e-6);
     a.bound2_f = (float)(bound * bound);
     a.nblocks = choose_blocks(ctx, s->n);
-    unsigned long long *d = nullptr, h[8];
+    unsigned long long *d = nullptr, h[11];
     HIP_TRY(hipMalloc(&d, sizeof h));
     HIP_TRY(hipMemsetAsync(d, 0, sizeof h, ctx->stream));
     hipLaunchKernelGGL(k_nn_counters, dim3(a.nblocks), dim3(256), 0, ctx->stream, a, d);
@@ -650,6 +664,6 @@ extern "C" pcr_status pcr_nn_counters(pcr_target *t, pcr_scan *s, const double T
     HIP_TRY(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipFree(d));
-    for (int i = 0; i < 8; ++i) out[i] = (double)h[i];
+    for (int i = 0; i < 11; ++i) out[i] = (double)h[i];
     return PCR_OK;
 }
