@@ -212,6 +212,13 @@ def main():
                          "bytes_per_point": B_ALG[kind_name]},
             "kernels": {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 5)} for k, v in kern.items()},
         }
+        if "reduce" in kern:
+            # SURVEY.md section 8d asks for the streaming kernel on its own: B_alg + the 4-byte index per point
+            k2 = (B_ALG[kind_name] + 4) * sc.n / (kern["reduce"]["avg_ms"] * 1e-3) / 1e9
+            line["roofline_reduce_kernel"] = {"bound": "hbm", "achieved": round(k2, 3), "peak": HBM_PEAK_GBS,
+                                              "unit": "GB/s", "frac": round(k2 / HBM_PEAK_GBS, 6),
+                                              "bytes_per_point": B_ALG[kind_name] + 4,
+                                              "kernel_ms": round(kern["reduce"]["avg_ms"], 5)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(kind_name, target, scan, tgt, traj, max_dist, voxel_size,
                                                 args.cpu_passes)

@@ -49,7 +49,6 @@ struct LinArgs {
     int nblocks;
     double *partials;  // [nblocks][32]
     // variant 1: correspondences through HBM
-    float *nn_dist;
     uint32_t *nn_j;
     uint32_t *tile_ctr;   // 8 per-XCD tile counters (64 B apart) for k_nn_scan's dynamic scheduling
 };
@@ -514,7 +513,7 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
     a.flags = flags;
     a.nblocks = choose_blocks(ctx, s->n);
     a.partials = ctx->d_partials;
-    a.nn_dist = nullptr; a.nn_j = ctx->d_nn_j; a.tile_ctr = ctx->d_tile_ctr;
+    a.nn_j = ctx->d_nn_j; a.tile_ctr = ctx->d_tile_ctr;
 
     if (ctx->variant == 1 && a.nblocks > ctx->num_cu * 4) a.nblocks = ctx->num_cu * 4;   // k_reduce streams: 4 blocks/CU
     ProfEvent ev;

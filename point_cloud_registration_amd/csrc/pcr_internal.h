@@ -72,7 +72,6 @@ struct pcr_context {
     double *h_out_dev = nullptr;    // device-side address of h_out
     uint32_t seq = 0;
     // variant-1 scratch (NN results in HBM)
-    float *d_nn_dist = nullptr;
     uint32_t *d_nn_j = nullptr;
     int64_t nn_cap = 0;
     int variant = 0;
