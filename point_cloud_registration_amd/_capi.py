@@ -82,7 +82,13 @@ def _share_hip_runtime_with_torch():
     by path; if libpcr_hip.so has already pulled in /opt/rocm's copy, a later ``import torch`` leaves
     TWO runtimes in the process (observed: "double free or corruption" at exit).  When torch is
     installed but not imported yet, load its runtime first so both sides resolve to the same one
-    (same SONAME, libamdhip64.so.7).  PCR_KEEP_SYSTEM_HIP=1 skips this."""
+    (same SONAME, libamdhip64.so.7).  PCR_KEEP_SYSTEM_HIP=1 skips this.
+
+    Everything is loaded with RTLD_LOCAL: the loader reuses an already-loaded object by SONAME / inode
+    whatever its scope, and putting RCCL's dependency librocm_smi64.so into the GLOBAL scope makes a
+    later libamd_smi.so (loaded by ``import torch`` through the amdsmi module) bind its static
+    ``amd::smi`` maps to librocm_smi64's copies -- constructed twice, destroyed twice, glibc aborts
+    at exit (reproducible with six lines of ctypes, no libpcr involved)."""
     import importlib.util
     import sys
     if "torch" in sys.modules or os.environ.get("PCR_KEEP_SYSTEM_HIP"):
@@ -98,7 +104,7 @@ def _share_hip_runtime_with_torch():
     path = os.path.join(libdir, "libamdhip64.so")
     if os.path.exists(path):
         try:
-            C.CDLL(path, mode=C.RTLD_GLOBAL)
+            C.CDLL(path, mode=C.RTLD_LOCAL)
             _torch_lib_dir = libdir
         except OSError:
             pass
@@ -112,7 +118,7 @@ def _share_rccl_with_torch():
     path = os.path.join(_torch_lib_dir, "librccl.so")
     if os.path.exists(path):
         try:
-            C.CDLL(path, mode=C.RTLD_GLOBAL)
+            C.CDLL(path, mode=C.RTLD_LOCAL)
         except OSError:
             pass
 
@@ -127,7 +133,7 @@ def lib():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the registration hot path.")
     _share_hip_runtime_with_torch()
-    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(L, name)          # AttributeError if the symbol is not exported
         fn.restype = res

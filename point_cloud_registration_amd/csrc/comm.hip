@@ -26,7 +26,9 @@ static pcr_status load_rccl() {
     if (g_nccl.lib) return PCR_OK;
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *lib = nullptr;
-    for (const char *n : names) { lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+    // RTLD_LOCAL on purpose: RCCL's dependency librocm_smi64.so must stay out of the global scope,
+    // or a libamd_smi.so loaded later (e.g. by `import torch`) interposes its static maps onto it
+    for (const char *n : names) { lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
     if (!lib) { pcr_set_error("cannot load RCCL: %s", dlerror()); return PCR_ERR_COMM; }
     g_nccl.GetUniqueId = (decltype(g_nccl.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
     g_nccl.CommInitRank = (decltype(g_nccl.CommInitRank))dlsym(lib, "ncclCommInitRank");

@@ -65,3 +65,20 @@ def test_two_ranks_one_gpu_sharded_plane_icp(g2):
     final = g2["align_plane_final"]
     assert np.max(np.abs(Ta[:3, 3] - final[:3, 3])) < 1e-4
     assert np.max(np.abs(Ha - g2["T_plane_H"])) < 1e-5 * np.max(np.abs(g2["T_plane_H"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", ["rccl_then_torch", "torch_then_rccl"])
+def test_process_exits_cleanly_with_rccl_and_torch(order):
+    """Interpreter exit after RCCL was used through libpcr_hip.so AND torch was imported, in either
+    order: must be exit code 0 (regression: librocm_smi64.so in the global symbol scope clashed with
+    torch's libamd_smi.so -> 'double free or corruption' in a static destructor)."""
+    import subprocess
+    import sys
+    body = ("from point_cloud_registration_amd import _capi\n"
+            "ctx = _capi.get_context(0)\n"
+            "ctx.comm_init(_capi.comm_unique_id(), 1, 0); ctx.comm_destroy()\n")
+    torch_part = "import torch\ntorch.zeros(4).cuda(); torch.cuda.synchronize()\n"
+    code = f"import sys; sys.path.insert(0, {REPO!r})\n" + (body + torch_part if order == "rccl_then_torch" else torch_part + body)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
