@@ -151,11 +151,13 @@ extern "C" pcr_status pcr_profile_read(pcr_context *ctx, int64_t launches[PCR_K_
 template <typename T>
 static pcr_status upload(pcr_context *ctx, const T *host, size_t count, T **dev) {
     *dev = nullptr;
-    HIP_TRY(hipMalloc(dev, sizeof(T) * (count ? count : 1)));
+    DevBuf<T> buf;
+    HIP_TRY(buf.alloc(count));
     if (count) {
-        HIP_TRY(hipMemcpyAsync(*dev, host, sizeof(T) * count, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(buf.p, host, sizeof(T) * count, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
+    *dev = buf.release();
     return PCR_OK;
 }
 
@@ -237,13 +239,13 @@ extern "C" pcr_status pcr_target_get_normals(pcr_target *t, float *normals_out) 
     pcr_context *ctx = t->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     if (t->n == 0) return PCR_OK;
-    float *d_out = nullptr;
-    HIP_TRY(hipMalloc(&d_out, sizeof(float) * 3 * (size_t)t->n));
+    DevBuf<float> d_out;
+    HIP_TRY(d_out.alloc(3 * (size_t)t->n));
     hipLaunchKernelGGL(k_unpermute_normals, dim3((unsigned)((t->n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       t->normals, t->pts, t->n, d_out);
-    HIP_TRY(hipMemcpyAsync(normals_out, d_out, sizeof(float) * 3 * (size_t)t->n, hipMemcpyDeviceToHost, ctx->stream));
+                       t->normals, t->pts, t->n, d_out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(normals_out, d_out.p, sizeof(float) * 3 * (size_t)t->n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(d_out));
     return PCR_OK;
 }
 

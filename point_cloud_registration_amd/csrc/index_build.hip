@@ -66,8 +66,8 @@ __global__ void __launch_bounds__(256) k_bbox(const T *__restrict__ xyz, int64_t
 
 template <typename T>
 static pcr_status device_bbox(pcr_context *ctx, const T *d_xyz, int64_t n, float lo[3], float hi[3]) {
-    unsigned *d_box = nullptr;
-    HIP_TRY(hipMalloc(&d_box, 6 * sizeof(unsigned)));
+    DevBuf<unsigned> d_box;
+    HIP_TRY(d_box.alloc(6));
     unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     HIP_TRY(hipMemcpyAsync(d_box, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
     if (n > 0) {
@@ -78,7 +78,6 @@ static pcr_status device_bbox(pcr_context *ctx, const T *d_xyz, int64_t n, float
     unsigned h[6];
     HIP_TRY(hipMemcpyAsync(h, d_box, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(d_box));
     for (int a = 0; a < 3; ++a) {
         lo[a] = n > 0 ? ord2f(h[a]) : 0.f;
         hi[a] = n > 0 ? ord2f(h[3 + a]) : 0.f;
@@ -183,19 +182,18 @@ __global__ void __launch_bounds__(256) k_gap_pack(uint32_t *cs, int64_t ncells, 
 
 static pcr_status pack_gap_field(pcr_context *ctx, uint32_t *cs, int nx, int ny, int nz, uint32_t **seed_out) {
     const int64_t ncells = (int64_t)nx * ny * nz;
-    uint8_t *gap = nullptr;
-    uint32_t *seed = nullptr;
-    HIP_TRY(hipMalloc(&gap, (size_t)ncells));
-    HIP_TRY(hipMalloc(&seed, 4 * (size_t)ncells));
-    *seed_out = seed;
+    DevBuf<uint8_t> gap;
+    DevBuf<uint32_t> seed;
+    HIP_TRY(gap.alloc((size_t)ncells));
+    HIP_TRY(seed.alloc((size_t)ncells));
     const unsigned nb = (unsigned)((ncells + 255) / 256);
-    hipLaunchKernelGGL(k_gap_init, dim3(nb), dim3(256), 0, ctx->stream, cs, ncells, gap, seed);
+    hipLaunchKernelGGL(k_gap_init, dim3(nb), dim3(256), 0, ctx->stream, cs, ncells, gap.p, seed.p);
     for (int t = 1; t <= PCR_GAP_MAX; ++t)
-        hipLaunchKernelGGL(k_gap_step, dim3(nb), dim3(256), 0, ctx->stream, gap, seed, nx, ny, nz, t);
-    hipLaunchKernelGGL(k_gap_pack, dim3(nb), dim3(256), 0, ctx->stream, cs, ncells, gap);
+        hipLaunchKernelGGL(k_gap_step, dim3(nb), dim3(256), 0, ctx->stream, gap.p, seed.p, nx, ny, nz, t);
+    hipLaunchKernelGGL(k_gap_pack, dim3(nb), dim3(256), 0, ctx->stream, cs, ncells, (const uint8_t *)gap.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(gap));
+    *seed_out = seed.release();
     return PCR_OK;
 }
 
@@ -221,11 +219,10 @@ static bool make_geom(const float lo[3], const float hi[3], double h, Geom<Real>
 static pcr_status exclusive_scan_u32(pcr_context *ctx, uint32_t *d_inout, int64_t n) {
     size_t tmp_bytes = 0;
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_inout, d_inout, (int)n, ctx->stream));
-    void *tmp = nullptr;
-    HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, d_inout, d_inout, (int)n, ctx->stream));
+    DevBuf<char> tmp;
+    HIP_TRY(tmp.alloc_bytes(tmp_bytes));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, d_inout, d_inout, (int)n, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(tmp));
     return PCR_OK;
 }
 
@@ -235,12 +232,11 @@ static pcr_status sort_pairs(pcr_context *ctx, K *keys_in, K *keys_out, uint32_t
     size_t tmp_bytes = 0;
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, end_bit,
                                                ctx->stream));
-    void *tmp = nullptr;
-    HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, end_bit,
+    DevBuf<char> tmp;
+    HIP_TRY(tmp.alloc_bytes(tmp_bytes));
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, end_bit,
                                                ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(tmp));
     return PCR_OK;
 }
 
@@ -264,9 +260,9 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const double max_cells = fmin(1.0e9, (double)free_b / 4.0 / 8.0);   // cell_start may take 1/8 of free HBM
 
-    uint32_t *d_counts = nullptr;
-    unsigned long long *d_nz = nullptr;
-    HIP_TRY(hipMalloc(&d_nz, sizeof(unsigned long long)));
+    DevBuf<uint32_t> d_counts;
+    DevBuf<unsigned long long> d_nz;
+    HIP_TRY(d_nz.alloc(1));
     double ncells = 0;
     int64_t occupied = 0;
     const unsigned nb = (unsigned)((n + 255) / 256);
@@ -275,16 +271,16 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
     for (int iter = 0; iter < 16; ++iter) {
         Geom<Real> g;
         while (!make_geom<Real>(lo, hi, h, &g, &ncells) || ncells > max_cells) { h *= 2.0; capped = true; }
-        if (d_counts) { HIP_TRY(hipFree(d_counts)); d_counts = nullptr; }
-        HIP_TRY(hipMalloc(&d_counts, sizeof(uint32_t) * ((size_t)ncells + 1)));
-        HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * ((size_t)ncells + 1), ctx->stream));
+        HIP_TRY(d_counts.alloc((size_t)ncells + 1));
+        HIP_TRY(hipMemsetAsync(d_counts.p, 0, sizeof(uint32_t) * ((size_t)ncells + 1), ctx->stream));
         if (n > 0)
             hipLaunchKernelGGL((k_cell_ids<Real, T>), dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, g,
-                               (uint32_t *)nullptr, (uint32_t *)nullptr, d_counts);
-        HIP_TRY(hipMemsetAsync(d_nz, 0, sizeof(unsigned long long), ctx->stream));
-        hipLaunchKernelGGL(k_count_nonzero, dim3(1024), dim3(256), 0, ctx->stream, d_counts, (int64_t)ncells, d_nz);
+                               (uint32_t *)nullptr, (uint32_t *)nullptr, d_counts.p);
+        HIP_TRY(hipMemsetAsync(d_nz.p, 0, sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(k_count_nonzero, dim3(1024), dim3(256), 0, ctx->stream, (const uint32_t *)d_counts.p,
+                           (int64_t)ncells, d_nz.p);
         unsigned long long nz = 0;
-        HIP_TRY(hipMemcpyAsync(&nz, d_nz, sizeof nz, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(&nz, d_nz.p, sizeof nz, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         occupied = (int64_t)nz;
         if (!auto_h || n == 0) break;
@@ -293,7 +289,6 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
         if (occ < 2.5 && dir >= 0) { h *= 2.0; dir = 1; continue; }
         break;
     }
-    HIP_TRY(hipFree(d_nz));
     if (auto_h && n > 0 && occupied > 0 && !capped) {
         // fine adjustment: clouds are surfaces, so occupancy of occupied cells grows like h^2; aim at
         // ~5 points per cell (measured optimum on MI355X: fewer candidates per ring-0 cell, still few rows)
@@ -307,15 +302,14 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
     make_geom<Real>(lo, hi, h, &g, &ncells);
     while (ncells > max_cells) { h *= 2.0; make_geom<Real>(lo, hi, h, &g, &ncells); }
     *geom = g;
-    if (d_counts) HIP_TRY(hipFree(d_counts));
-    HIP_TRY(hipMalloc(&d_counts, sizeof(uint32_t) * ((size_t)ncells + 1)));
-    HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * ((size_t)ncells + 1), ctx->stream));
-    uint32_t *d_cid = nullptr, *d_idx = nullptr, *d_cid2 = nullptr, *d_idx2 = nullptr;
+    HIP_TRY(d_counts.alloc((size_t)ncells + 1));
+    HIP_TRY(hipMemsetAsync(d_counts.p, 0, sizeof(uint32_t) * ((size_t)ncells + 1), ctx->stream));
+    DevBuf<uint32_t> d_cid, d_idx, d_cid2, d_idx2, d_seed;
     const size_t nn = (size_t)(n > 0 ? n : 1);
-    HIP_TRY(hipMalloc(&d_cid, 4 * nn)); HIP_TRY(hipMalloc(&d_idx, 4 * nn));
-    HIP_TRY(hipMalloc(&d_cid2, 4 * nn)); HIP_TRY(hipMalloc(&d_idx2, 4 * nn));
-    PT *d_pts = nullptr;
-    HIP_TRY(hipMalloc(&d_pts, sizeof(PT) * (nn + PCR_PTS_PAD)));
+    HIP_TRY(d_cid.alloc(nn)); HIP_TRY(d_idx.alloc(nn));
+    HIP_TRY(d_cid2.alloc(nn)); HIP_TRY(d_idx2.alloc(nn));
+    DevBuf<PT> d_pts;
+    HIP_TRY(d_pts.alloc(nn + PCR_PTS_PAD));
     {   // sentinel records behind the last point (see nn_scan_range): +inf coordinates, index ~0
         PT pad[PCR_PTS_PAD];
         for (int i = 0; i < PCR_PTS_PAD; ++i) {
@@ -323,43 +317,44 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
             if (sizeof(Real) == 4) { const uint32_t m = 0xffffffffu; memcpy(&pad[i].w, &m, 4); }
             else { const long long m = 0xffffffffLL; memcpy(&pad[i].w, &m, 8); }
         }
-        HIP_TRY(hipMemcpyAsync(d_pts + (size_t)n, pad, sizeof pad, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(d_pts.p + (size_t)n, pad, sizeof pad, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     if (n > 0) {
-        hipLaunchKernelGGL((k_cell_ids<Real, T>), dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, g, d_cid, d_idx, d_counts);
+        hipLaunchKernelGGL((k_cell_ids<Real, T>), dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, g, d_cid.p, d_idx.p,
+                           d_counts.p);
         PCR_TRY(sort_pairs<uint32_t>(ctx, d_cid, d_cid2, d_idx, d_idx2, n, bits_for(ncells)));
         if (sizeof(Real) == 4)
-            hipLaunchKernelGGL(k_gather_f32, dim3(nb), dim3(256), 0, ctx->stream, (const float *)d_xyz, d_idx2, n, (PtF *)d_pts);
+            hipLaunchKernelGGL(k_gather_f32, dim3(nb), dim3(256), 0, ctx->stream, (const float *)d_xyz,
+                               (const uint32_t *)d_idx2.p, n, (PtF *)d_pts.p);
         else
-            hipLaunchKernelGGL(k_gather_f64, dim3(nb), dim3(256), 0, ctx->stream, (const double *)d_xyz, d_idx2, n, (PtD *)d_pts);
+            hipLaunchKernelGGL(k_gather_f64, dim3(nb), dim3(256), 0, ctx->stream, (const double *)d_xyz,
+                               (const uint32_t *)d_idx2.p, n, (PtD *)d_pts.p);
     }
     PCR_TRY(exclusive_scan_u32(ctx, d_counts, (int64_t)ncells + 1));
     if (n > 0 && n < ((int64_t)1 << PCR_GAP_SHIFT)) {
-        uint32_t *seed = nullptr;
-        PCR_TRY(pack_gap_field(ctx, d_counts, g.nx, g.ny, g.nz, &seed));
+        PCR_TRY(pack_gap_field(ctx, d_counts, g.nx, g.ny, g.nz, &d_seed.p));
         g.cs_mask = (1u << PCR_GAP_SHIFT) - 1u;
-        g.seed = seed;
-        *geom = g;
-        *seed_out = seed;
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(d_cid)); HIP_TRY(hipFree(d_idx)); HIP_TRY(hipFree(d_cid2)); HIP_TRY(hipFree(d_idx2));
     // occupied cells for the final geometry
     if (n > 0) {
-        unsigned long long *d_nz2 = nullptr, nz2 = 0;
-        HIP_TRY(hipMalloc(&d_nz2, sizeof(unsigned long long)));
-        HIP_TRY(hipMemsetAsync(d_nz2, 0, sizeof(unsigned long long), ctx->stream));
-        hipLaunchKernelGGL(k_count_occupied, dim3(1024), dim3(256), 0, ctx->stream, d_counts, (int64_t)ncells, g.cs_mask, d_nz2);
-        HIP_TRY(hipMemcpyAsync(&nz2, d_nz2, sizeof nz2, hipMemcpyDeviceToHost, ctx->stream));
+        unsigned long long nz2 = 0;
+        HIP_TRY(hipMemsetAsync(d_nz.p, 0, sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(k_count_occupied, dim3(1024), dim3(256), 0, ctx->stream, (const uint32_t *)d_counts.p,
+                           (int64_t)ncells, g.cs_mask, d_nz.p);
+        HIP_TRY(hipMemcpyAsync(&nz2, d_nz.p, sizeof nz2, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        HIP_TRY(hipFree(d_nz2));
         occupied = (int64_t)nz2;
     }
+    // success: hand the index over
+    g.seed = d_seed.p;
+    *geom = g;
+    *seed_out = d_seed.release();
     *occupied_out = occupied;
-    *cell_start_out = d_counts;
-    *pts_out = d_pts;
+    *cell_start_out = d_counts.release();
+    *pts_out = d_pts.release();
     return PCR_OK;
 }
 
@@ -464,15 +459,14 @@ pcr_status pcr_sort_scan(pcr_context *ctx, const float *d_xyz, int64_t n, unsign
     float ext = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
     if (!(ext > 0)) ext = 1.f;
     const float scale = 2097151.f / ext;
-    unsigned long long *k1 = nullptr, *k2 = nullptr;
-    uint32_t *i1 = nullptr, *i2 = nullptr;
-    HIP_TRY(hipMalloc(&k1, 8 * nn)); HIP_TRY(hipMalloc(&k2, 8 * nn));
-    HIP_TRY(hipMalloc(&i1, 4 * nn)); HIP_TRY(hipMalloc(&i2, 4 * nn));
-    hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, lo[0], lo[1], lo[2], scale, k1, i1);
+    DevBuf<unsigned long long> k1, k2;
+    DevBuf<uint32_t> i1, i2;
+    HIP_TRY(k1.alloc(nn)); HIP_TRY(k2.alloc(nn));
+    HIP_TRY(i1.alloc(nn)); HIP_TRY(i2.alloc(nn));
+    hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, lo[0], lo[1], lo[2], scale, k1.p, i1.p);
     PCR_TRY(sort_pairs<unsigned long long>(ctx, k1, k2, i1, i2, n, 63));
-    hipLaunchKernelGGL(k_to_soa, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, i2, n, s->x, s->y, s->z);
+    hipLaunchKernelGGL(k_to_soa, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, (const uint32_t *)i2.p, n, s->x, s->y, s->z);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(k1)); HIP_TRY(hipFree(k2)); HIP_TRY(hipFree(i1)); HIP_TRY(hipFree(i2));
     return PCR_OK;
 }

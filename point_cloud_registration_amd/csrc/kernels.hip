@@ -655,14 +655,14 @@ extern "C" pcr_status pcr_nn_counters(pcr_target *t, pcr_scan *s, const double T
     const double bound = max_dist * (1.0 + 1e-6);
     a.bound2_f = (float)(bound * bound);
     a.nblocks = choose_blocks(ctx, s->n);
-    unsigned long long *d = nullptr, h[11];
-    HIP_TRY(hipMalloc(&d, sizeof h));
-    HIP_TRY(hipMemsetAsync(d, 0, sizeof h, ctx->stream));
-    hipLaunchKernelGGL(k_nn_counters, dim3(a.nblocks), dim3(256), 0, ctx->stream, a, d);
+    unsigned long long h[11];
+    DevBuf<unsigned long long> d;
+    HIP_TRY(d.alloc(11));
+    HIP_TRY(hipMemsetAsync(d.p, 0, sizeof h, ctx->stream));
+    hipLaunchKernelGGL(k_nn_counters, dim3(a.nblocks), dim3(256), 0, ctx->stream, a, d.p);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(h, d.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(d));
     for (int i = 0; i < 11; ++i) out[i] = (double)h[i];
     return PCR_OK;
 }

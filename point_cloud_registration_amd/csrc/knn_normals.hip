@@ -188,20 +188,19 @@ extern "C" pcr_status pcr_knn_query(pcr_target *t, const float *q, int64_t m, in
     pcr_context *ctx = t->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     if (m == 0) return PCR_OK;
-    float *d_q = nullptr, *d_dist = nullptr;
-    int64_t *d_idx = nullptr;
-    HIP_TRY(hipMalloc(&d_q, 12 * (size_t)m));
-    HIP_TRY(hipMalloc(&d_dist, 4 * (size_t)m * k));
-    HIP_TRY(hipMalloc(&d_idx, 8 * (size_t)m * k));
-    HIP_TRY(hipMemcpyAsync(d_q, q, 12 * (size_t)m, hipMemcpyHostToDevice, ctx->stream));
+    DevBuf<float> d_q, d_dist;
+    DevBuf<int64_t> d_idx;
+    HIP_TRY(d_q.alloc(3 * (size_t)m));
+    HIP_TRY(d_dist.alloc((size_t)m * k));
+    HIP_TRY(d_idx.alloc((size_t)m * k));
+    HIP_TRY(hipMemcpyAsync(d_q.p, q, 12 * (size_t)m, hipMemcpyHostToDevice, ctx->stream));
     const size_t smem = 3 * sizeof(float) * (size_t)k * KNN_BLOCK;
     hipLaunchKernelGGL(k_knn_query, dim3((unsigned)((m + KNN_BLOCK - 1) / KNN_BLOCK)), dim3(KNN_BLOCK), smem, ctx->stream,
-                       t->gf, t->pts, t->cell_start, t->n, d_q, m, k, d_dist, d_idx);
+                       t->gf, t->pts, t->cell_start, t->n, (const float *)d_q.p, m, k, d_dist.p, d_idx.p);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(dist, d_dist, 4 * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(idx, d_idx, 8 * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dist, d_dist.p, 4 * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(idx, d_idx.p, 8 * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(d_q)); HIP_TRY(hipFree(d_dist)); HIP_TRY(hipFree(d_idx));
     return PCR_OK;
 }
 

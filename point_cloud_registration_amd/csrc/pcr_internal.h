@@ -55,6 +55,35 @@ struct Geom {
 typedef float4 PtF;
 typedef double4 PtD;
 
+// Device allocation released on scope exit unless handed over with release(): every early return
+// of the HIP_TRY / PCR_TRY macros leaves no temporaries behind.
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { reset(); }
+    hipError_t alloc(size_t count) {
+        reset();
+        return hipMalloc(&p, sizeof(T) * (count ? count : 1));
+    }
+    hipError_t alloc_bytes(size_t bytes) {
+        reset();
+        return hipMalloc(&p, bytes ? bytes : 16);
+    }
+    void reset() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+    T *release() {
+        T *q = p;
+        p = nullptr;
+        return q;
+    }
+    operator T *() const { return p; }
+};
+
 struct ProfEvent {
     int kernel;
     hipEvent_t start, stop;

@@ -162,17 +162,17 @@ extern "C" pcr_status pcr_target_voxels_create(pcr_context *ctx, const void *xyz
     PCR_REQUIRE(voxel_size > 0, "voxel_size must be positive");
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t elem = xyz_is_f64 ? 8 : 4;
-    void *d_xyz = nullptr;
-    HIP_TRY(hipMalloc(&d_xyz, elem * 3 * (size_t)(n > 0 ? n : 1)));
+    DevBuf<char> d_xyz;
+    HIP_TRY(d_xyz.alloc_bytes(elem * 3 * (size_t)(n > 0 ? n : 1)));
     if (n > 0) {
-        HIP_TRY(hipMemcpyAsync(d_xyz, xyz, elem * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(d_xyz.p, xyz, elem * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     pcr_target *t = new pcr_target();
     t->ctx = ctx; t->is_voxel = 1;
-    pcr_status s = xyz_is_f64 ? voxel_build<double>(ctx, (const double *)d_xyz, n, voxel_size, min_points, t)
-                              : voxel_build<float>(ctx, (const float *)d_xyz, n, voxel_size, min_points, t);
-    (void)hipFree(d_xyz);
+    pcr_status s = xyz_is_f64 ? voxel_build<double>(ctx, (const double *)d_xyz.p, n, voxel_size, min_points, t)
+                              : voxel_build<float>(ctx, (const float *)d_xyz.p, n, voxel_size, min_points, t);
+    d_xyz.reset();
     if (s != PCR_OK) { pcr_target_destroy(t); return s; }
     *out = t;
     return PCR_OK;
