@@ -43,12 +43,14 @@ extern "C" pcr_status pcr_context_create(int device, pcr_context **out) {
         return PCR_ERR_INVALID;
     }
     HIP_TRY(hipSetDevice(device));
-    pcr_context *ctx = new pcr_context();
-    ctx->device = device;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
+    hipStream_t stream = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    pcr_context *ctx = new pcr_context();
+    ctx->device = device;
     ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->stream = stream;
     ctx->variant = 1;      // measured on MI355X: NN kernel + reduce kernel beats the fused kernel (occupancy)
     const char *v = getenv("PCR_VARIANT");
     if (v) ctx->variant = atoi(v) == 0 ? 0 : 1;
@@ -215,13 +217,12 @@ extern "C" pcr_status pcr_target_set_normals(pcr_target *t, const float *normals
     PCR_REQUIRE(!t->is_voxel, "normals belong to point targets");
     pcr_context *ctx = t->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
-    float *d_nrm = nullptr;
-    PCR_TRY(upload<float>(ctx, normals, (size_t)t->n * 3, &d_nrm));
+    DevBuf<float> d_nrm;
+    PCR_TRY(upload<float>(ctx, normals, (size_t)t->n * 3, &d_nrm.p));
     if (!t->normals) HIP_TRY(hipMalloc(&t->normals, sizeof(float4) * (size_t)(t->n ? t->n : 1)));
-    pcr_status s = pcr_permute_rows_f32(ctx, d_nrm, t->n, 3, t->pts, t->normals);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_nrm);
-    return s;
+    PCR_TRY(pcr_permute_rows_f32(ctx, d_nrm.p, t->n, 3, t->pts, t->normals));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PCR_OK;
 }
 
 __global__ void __launch_bounds__(256) k_unpermute_normals(const float4 *__restrict__ nrm, const PtF *__restrict__ pts,
