@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: M-correspondences/s of the registration hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config plane_b01|icp_b01|vplane_10m|ndt_10m|plane_100m]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config plane_b01|icp_b01|icp_b01_harness|plane_b01_100k|vplane_10m|ndt_10m|plane_100m]
 
 A "step" is ONE pass of the hot path -- one ``calc_H_g_e2``: float32 transform of the whole
 scan shard, exact nearest-neighbour search against the target, the ``dist < max_dist`` gate,
@@ -41,7 +41,11 @@ CONFIGS = {
                   "Point-to-Plane ICP (PlaneICP, k=15 normals), B-01 stand-in street(1.06M) vs perturbed scan"),
     "icp_b01": ("icp", 1_060_000, 1_060_000, None, "Point-to-Point ICP, B-01 stand-in street(1.06M) vs perturbed scan"),
     "plane_b01_100k": ("plane", 1_060_000, 100_000, None,
-                       "Point-to-Plane ICP, B-01 stand-in, reference-harness 100k scan"),
+                       "Point-to-Plane ICP, B-01 stand-in, 100k-point perturbed scan"),
+    # BASELINE.json configs[0]: the reference harness' own case (benchmark/test_data.py:21-44)
+    "icp_b01_harness": ("icp", 1_060_000, 100_000, None,
+                        "Point-to-Point ICP, B-01 stand-in, reference-harness scan: 100k random points shifted "
+                        "by t=(0,0,0.3) + N(0,0.005) noise, init_T = I"),
     "vplane_10m": ("vplane", 10_000_000, 10_000_000, 0.5, "VPlaneICP voxel_size=0.5, synthetic 10M-pt cloud"),
     "ndt_10m": ("ndt", 10_000_000, 10_000_000, 1.0, "NDT voxel_size=1.0, synthetic 10M-pt cloud"),
     "plane_100m": ("plane", 100_000_000, 12_500_000, None,
@@ -76,7 +80,7 @@ def main():
     import torch                                   # first: one HIP runtime / one RCCL per process
     from point_cloud_registration_amd import _capi
     from point_cloud_registration_amd import distributed as pdist
-    from point_cloud_registration_amd.synthetic import perturbed_scan
+    from point_cloud_registration_amd.synthetic import harness_scan, perturbed_scan
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -117,7 +121,12 @@ def main():
         data_tag = "B-01.pcd"
     else:
         target = make_cloud(n_target, seed=0)
-    scan, T_true = perturbed_scan(target, n_scan if n_scan < n_target else None, seed=2 + rank)
+    if "harness" in args.config:
+        scan = harness_scan(target, n_scan, seed=1 + rank)
+        T_true = np.eye(4)
+        T_true[2, 3] = -0.3                                   # align(scan, I) undoes the +0.3 m shift
+    else:
+        scan, T_true = perturbed_scan(target, n_scan if n_scan < n_target else None, seed=2 + rank)
     if kind_name in ("icp", "plane"):
         tgt = _capi.Target.points(ctx, target)
         if kind_name == "plane":

@@ -23,7 +23,8 @@ def test_configs_match_baseline_json():
     base = json.load(open(os.path.join(REPO, "BASELINE.json")))
     assert "correspondences/sec" in base["metric"]
     # one bench config per BASELINE.json config line
-    assert {"plane_b01", "plane_b01_100k", "vplane_10m", "ndt_10m", "plane_100m"} <= set(bench.CONFIGS)
+    assert {"icp_b01_harness", "plane_b01", "vplane_10m", "ndt_10m", "plane_100m"} <= set(bench.CONFIGS)
+    assert bench.CONFIGS["icp_b01_harness"][0] == "icp" and bench.CONFIGS["icp_b01_harness"][2] == 100_000
     assert bench.CONFIGS["plane_b01"][0] == "plane" and bench.CONFIGS["plane_b01"][1] == 1_060_000
     assert bench.CONFIGS["vplane_10m"][3] == 0.5 and bench.CONFIGS["ndt_10m"][3] == 1.0
     assert bench.B_ALG == {"icp": 24, "plane": 36, "vplane": 36, "ndt": 48}
