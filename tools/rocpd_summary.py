@@ -20,7 +20,7 @@ for path in sys.argv[1:]:
     print(f"== {path}")
     rows = cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
     if rows:
-        print(f"{'kernel':<112} {'calls':>6} {'total_us':>12} {'avg_us':>10} {'%':>6}")
+        print(f"{'kernel':<112} {'calls':>6} {'total_ms':>12} {'avg_ms':>10} {'%':>6}")
         agg = {}
         for name, calls, tot, avg, pct in rows:
             k = short(name)
