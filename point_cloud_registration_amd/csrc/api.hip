@@ -54,6 +54,8 @@ extern "C" pcr_status pcr_context_create(int device, pcr_context **out) {
     ctx->variant = 1;      // measured on MI355X: NN kernel + reduce kernel beats the fused kernel (occupancy)
     const char *v = getenv("PCR_VARIANT");
     if (v) ctx->variant = atoi(v) == 0 ? 0 : 1;
+    const char *ff = getenv("PCR_FUSE_FINALIZE");
+    if (ff && *ff) ctx->fuse_finalize = atoi(ff) != 0;
     *out = ctx;
     return PCR_OK;
 }

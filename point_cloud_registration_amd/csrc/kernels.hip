@@ -193,6 +193,9 @@ __device__ __forceinline__ void wave_fold32(double *acc, int lane) {
     acc[0] += shfl_xor_f64(acc[0], 1);
 }
 
+// COHERENT: the store is written through to memory at agent scope, so that a block on ANOTHER XCD
+// (each XCD has a private, mutually non-coherent L2) can read it inside the same kernel.
+template <bool COHERENT = false>
 __device__ __forceinline__ void block_store_partials(double *acc, double *__restrict__ partials) {
     __shared__ double wsum[4][32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -201,7 +204,9 @@ __device__ __forceinline__ void block_store_partials(double *acc, double *__rest
     __syncthreads();
     if (threadIdx.x < 32) {
         const double s = ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
-        partials[(size_t)blockIdx.x * 32 + threadIdx.x] = s;
+        double *dst = &partials[(size_t)blockIdx.x * 32 + threadIdx.x];
+        if (COHERENT) __hip_atomic_store(dst, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *dst = s;
     }
 }
 
@@ -327,27 +332,10 @@ __global__ void __launch_bounds__(256) k_nn_counters(const LinArgs a, unsigned l
     if ((threadIdx.x & 63) == 0) for (int c = 0; c < 3; ++c) atomicAdd(&out[8 + c], cyc[c]);
 }
 
-template <int KIND>
-__global__ void __launch_bounds__(256) k_reduce(const LinArgs a) {
-    double acc[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-    const TileIter it(a);
-    for (int64_t i = it.base; i < it.end; i += it.stride) {
-        const uint32_t j = a.nn_j[i];
-        if (j == PCR_NONE) continue;
-        const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
-        float tx, ty, tz;
-        xform(a, x, y, z, tx, ty, tz);
-        accumulate<KIND>(acc, a, j, x, y, z, tx, ty, tz);
-    }
-    block_store_partials(acc, a.partials);
-}
-
 // ---- fold the per-block partials in a fixed order and emit the 29-vector ---------------------
 struct FinArgs {
     const double *partials;
-    uint32_t *tile_ctr;
+    uint32_t *tile_ctr;        // 8 tile counters (64 B apart) + the ticket of the fused variant at [8 * 16]
     int nblocks;
     int kind;
     double R[9];
@@ -357,20 +345,39 @@ struct FinArgs {
     uint32_t seq;
 };
 
-__global__ void __launch_bounds__(1024) k_finalize(const FinArgs f) {
+// Runs in ONE block of NT = 256 or 1024 threads; the order of additions does not depend on the block
+// size (so the stand-alone kernel and the variant fused into k_reduce give identical bits).
+// COHERENT: the partials were written by other blocks of the same kernel (agent-scope loads).
+template <bool COHERENT, int NT>
+__device__ __forceinline__ void finalize_body(const FinArgs &f) {
     __shared__ double part[32][33];
     __shared__ double tot[32];
-    const int c = threadIdx.x & 31, r = threadIdx.x >> 5;     // 32 row-groups x 32 components
-    // eight independent loads in flight per thread (a single dependent chain is pure latency)
-    double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int b0 = r; b0 < f.nblocks; b0 += 256) {
+    constexpr int RPT = 32 / (NT / 32);                        // row-groups per thread: 1 (1024 threads) or 4 (256)
+    const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;     // 32 row-groups x 32 components
+    // RPT x 8 independent loads in flight per thread (a single dependent chain is pure latency)
+    double s8[RPT][8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int b = b0 + 32 * u;
-            s8[u] += b < f.nblocks ? f.partials[(size_t)b * 32 + c] : 0.0;
+    for (int q = 0; q < RPT; ++q)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s8[q][u] = 0.0;
+    for (int b00 = 0; b00 < f.nblocks; b00 += 256) {
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b00 + r0 + q * (NT / 32) + 32 * u;
+                double v = 0.0;
+                if (b < f.nblocks) {
+                    const double *src = &f.partials[(size_t)b * 32 + c];
+                    v = COHERENT ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+                }
+                s8[q][u] += v;
+            }
         }
     }
-    part[r][c] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+#pragma unroll
+    for (int q = 0; q < RPT; ++q)
+        part[r0 + q * (NT / 32)][c] = ((s8[q][0] + s8[q][1]) + (s8[q][2] + s8[q][3])) + ((s8[q][4] + s8[q][5]) + (s8[q][6] + s8[q][7]));
     __syncthreads();
     if (threadIdx.x < 32) {
         double t = 0.0;
@@ -413,6 +420,56 @@ __global__ void __launch_bounds__(1024) k_finalize(const FinArgs f) {
     }
 }
 
+__global__ void __launch_bounds__(1024) k_finalize(const FinArgs f) { finalize_body<false, 1024>(f); }
+
+template <int KIND>
+__global__ void __launch_bounds__(256) k_reduce(const LinArgs a) {
+    double acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+    const TileIter it(a);
+    for (int64_t i = it.base; i < it.end; i += it.stride) {
+        const uint32_t j = a.nn_j[i];
+        if (j == PCR_NONE) continue;
+        const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
+        float tx, ty, tz;
+        xform(a, x, y, z, tx, ty, tz);
+        accumulate<KIND>(acc, a, j, x, y, z, tx, ty, tz);
+    }
+    block_store_partials(acc, a.partials);
+}
+
+// Small grids (<= 256 blocks): the block that takes the last ticket folds the partials itself, which
+// saves the separate k_finalize launch (~10 us + a launch gap of a ~75 us pass at 100 k points).  With
+// 1024 blocks the serialised tickets cost more than that launch (measured), hence two variants.
+template <int KIND>
+__global__ void __launch_bounds__(256) k_reduce_finalize(const LinArgs a, const FinArgs f) {
+    double acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+    const TileIter it(a);
+    for (int64_t i = it.base; i < it.end; i += it.stride) {
+        const uint32_t j = a.nn_j[i];
+        if (j == PCR_NONE) continue;
+        const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
+        float tx, ty, tz;
+        xform(a, x, y, z, tx, ty, tz);
+        accumulate<KIND>(acc, a, j, x, y, z, tx, ty, tz);
+    }
+    block_store_partials<true>(acc, a.partials);
+    __shared__ int last;
+    if (threadIdx.x == 0) {
+        // the 32 partial stores above were issued by this wave: wait for their completion, then take a ticket
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        const uint32_t t = __hip_atomic_fetch_add(&f.tile_ctr[8 * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = t == (uint32_t)(f.nblocks - 1);
+    }
+    __syncthreads();
+    if (!last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(&f.tile_ctr[8 * 16], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    finalize_body<true, 256>(f);
+}
+
 // after the RCCL all-reduce: hand the 29 doubles to the host the same zero-copy way k_finalize does
 __global__ void __launch_bounds__(64) k_publish(const double *__restrict__ out, double *host_out,
                                                 volatile uint32_t *host_flag, uint32_t seq) {
@@ -448,8 +505,8 @@ pcr_status pcr_ensure_scratch(pcr_context *ctx, int64_t n_points) {
         HIP_TRY(hipHostMalloc(&ctx->h_out, sizeof(double) * 40, hipHostMallocMapped | hipHostMallocCoherent));
         memset(ctx->h_out, 0, sizeof(double) * 40);
         HIP_TRY(hipHostGetDevicePointer((void **)&ctx->h_out_dev, ctx->h_out, 0));
-        HIP_TRY(hipMalloc(&ctx->d_tile_ctr, sizeof(uint32_t) * 8 * 16));
-        HIP_TRY(hipMemsetAsync(ctx->d_tile_ctr, 0, sizeof(uint32_t) * 8 * 16, ctx->stream));
+        HIP_TRY(hipMalloc(&ctx->d_tile_ctr, sizeof(uint32_t) * 9 * 16));       // 8 tile counters + 1 ticket
+        HIP_TRY(hipMemsetAsync(ctx->d_tile_ctr, 0, sizeof(uint32_t) * 9 * 16, ctx->stream));
         for (int v = 0; v < 2; ++v) {
             int nb = 0;
             hipError_t e = v == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<0>, 256, 0)
@@ -516,8 +573,22 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
     a.nn_j = ctx->d_nn_j; a.tile_ctr = ctx->d_tile_ctr;
 
     if (ctx->variant == 1 && a.nblocks > ctx->num_cu * 4) a.nblocks = ctx->num_cu * 4;   // k_reduce streams: 4 blocks/CU
+    // small scans: at most 256 reduce blocks, the last of which also folds the partials (k_reduce_finalize)
+    const bool fused_fin = ctx->variant == 1 && ctx->fuse_finalize && a.nblocks <= 512;
+    if (fused_fin && a.nblocks > 256) a.nblocks = 256;
     ProfEvent ev;
     const dim3 grid(a.nblocks), block(256);
+
+    FinArgs f;
+    f.partials = ctx->d_partials; f.tile_ctr = ctx->d_tile_ctr; f.nblocks = a.nblocks; f.kind = kind; f.out = ctx->d_out;
+    for (int i = 0; i < 9; ++i) f.R[i] = a.R[i];
+    // single GPU: the finalize step writes the result and a sequence number straight into pinned host
+    // memory (no copy command, no stream query); with a communicator the all-reduce sits in between
+    const bool direct = ctx->comm == nullptr && ctx->h_out_dev != nullptr;
+    volatile uint32_t *flag = (volatile uint32_t *)(ctx->h_out + 32);
+    f.host_out = direct ? ctx->h_out_dev : nullptr;
+    f.host_flag = direct ? (volatile uint32_t *)(ctx->h_out_dev + 32) : nullptr;
+    f.seq = ++ctx->seq;
     if (ctx->variant == 0) {
         pcr_prof_begin(ctx, PCR_K_LINEARIZE, &ev);
         switch (kind) {
@@ -541,30 +612,31 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
         }
         pcr_prof_end(ctx, &ev);
         pcr_prof_begin(ctx, PCR_K_REDUCE, &ev);
-        switch (kind) {
-        case PCR_ICP: hipLaunchKernelGGL(k_reduce<PCR_ICP>, grid, block, 0, ctx->stream, a); break;
-        case PCR_PLANE: hipLaunchKernelGGL(k_reduce<PCR_PLANE>, grid, block, 0, ctx->stream, a); break;
-        case PCR_VPLANE: hipLaunchKernelGGL(k_reduce<PCR_VPLANE>, grid, block, 0, ctx->stream, a); break;
-        default: hipLaunchKernelGGL(k_reduce<PCR_NDT>, grid, block, 0, ctx->stream, a); break;
+        if (fused_fin) {
+            switch (kind) {
+            case PCR_ICP: hipLaunchKernelGGL(k_reduce_finalize<PCR_ICP>, grid, block, 0, ctx->stream, a, f); break;
+            case PCR_PLANE: hipLaunchKernelGGL(k_reduce_finalize<PCR_PLANE>, grid, block, 0, ctx->stream, a, f); break;
+            case PCR_VPLANE: hipLaunchKernelGGL(k_reduce_finalize<PCR_VPLANE>, grid, block, 0, ctx->stream, a, f); break;
+            default: hipLaunchKernelGGL(k_reduce_finalize<PCR_NDT>, grid, block, 0, ctx->stream, a, f); break;
+            }
+        } else {
+            switch (kind) {
+            case PCR_ICP: hipLaunchKernelGGL(k_reduce<PCR_ICP>, grid, block, 0, ctx->stream, a); break;
+            case PCR_PLANE: hipLaunchKernelGGL(k_reduce<PCR_PLANE>, grid, block, 0, ctx->stream, a); break;
+            case PCR_VPLANE: hipLaunchKernelGGL(k_reduce<PCR_VPLANE>, grid, block, 0, ctx->stream, a); break;
+            default: hipLaunchKernelGGL(k_reduce<PCR_NDT>, grid, block, 0, ctx->stream, a); break;
+            }
         }
         pcr_prof_end(ctx, &ev);
     }
     HIP_TRY(hipGetLastError());
 
-    FinArgs f;
-    f.partials = ctx->d_partials; f.tile_ctr = ctx->d_tile_ctr; f.nblocks = a.nblocks; f.kind = kind; f.out = ctx->d_out;
-    for (int i = 0; i < 9; ++i) f.R[i] = a.R[i];
-    // single GPU: k_finalize writes the result and a sequence number straight into pinned host memory
-    // (no copy command, no stream query); with a communicator the all-reduce sits in between
-    const bool direct = ctx->comm == nullptr && ctx->h_out_dev != nullptr;
-    volatile uint32_t *flag = (volatile uint32_t *)(ctx->h_out + 32);
-    f.host_out = direct ? ctx->h_out_dev : nullptr;
-    f.host_flag = direct ? (volatile uint32_t *)(ctx->h_out_dev + 32) : nullptr;
-    f.seq = ++ctx->seq;
-    pcr_prof_begin(ctx, PCR_K_FINALIZE, &ev);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, ctx->stream, f);
-    pcr_prof_end(ctx, &ev);
-    HIP_TRY(hipGetLastError());
+    if (!fused_fin) {
+        pcr_prof_begin(ctx, PCR_K_FINALIZE, &ev);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, ctx->stream, f);
+        pcr_prof_end(ctx, &ev);
+        HIP_TRY(hipGetLastError());
+    }
 
     bool flagged = direct;
     if (ctx->comm) {
