@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(256) k_nn_counters(const LinArgs a, unsigned l
 // ---- fold the per-block partials in a fixed order and emit the 29-vector ---------------------
 struct FinArgs {
     const double *partials;
-    uint32_t *tile_ctr;        // 8 tile counters (64 B apart) + the ticket of the fused variant at [8 * 16]
+    uint32_t *tile_ctr;        // 64 B apart: [0..7] tile counters, [8..15] group tickets, [16] leader tickets
     int nblocks;
     int kind;
     double R[9];
@@ -345,46 +345,9 @@ struct FinArgs {
     uint32_t seq;
 };
 
-// Runs in ONE block of NT = 256 or 1024 threads; the order of additions does not depend on the block
-// size (so the stand-alone kernel and the variant fused into k_reduce give identical bits).
-// COHERENT: the partials were written by other blocks of the same kernel (agent-scope loads).
-template <bool COHERENT, int NT>
-__device__ __forceinline__ void finalize_body(const FinArgs &f) {
-    __shared__ double part[32][33];
-    __shared__ double tot[32];
-    constexpr int RPT = 32 / (NT / 32);                        // row-groups per thread: 1 (1024 threads) or 4 (256)
-    const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;     // 32 row-groups x 32 components
-    // RPT x 8 independent loads in flight per thread (a single dependent chain is pure latency)
-    double s8[RPT][8];
-#pragma unroll
-    for (int q = 0; q < RPT; ++q)
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s8[q][u] = 0.0;
-    for (int b00 = 0; b00 < f.nblocks; b00 += 256) {
-#pragma unroll
-        for (int q = 0; q < RPT; ++q) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int b = b00 + r0 + q * (NT / 32) + 32 * u;
-                double v = 0.0;
-                if (b < f.nblocks) {
-                    const double *src = &f.partials[(size_t)b * 32 + c];
-                    v = COHERENT ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
-                }
-                s8[q][u] += v;
-            }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < RPT; ++q)
-        part[r0 + q * (NT / 32)][c] = ((s8[q][0] + s8[q][1]) + (s8[q][2] + s8[q][3])) + ((s8[q][4] + s8[q][5]) + (s8[q][6] + s8[q][7]));
-    __syncthreads();
-    if (threadIdx.x < 32) {
-        double t = 0.0;
-        for (int k = 0; k < 32; ++k) t += part[k][threadIdx.x];
-        tot[threadIdx.x] = t;
-    }
-    __syncthreads();
+// tot[0..31] (shared memory, complete before the call) -> the 29-vector in HBM and, optionally, in
+// pinned host memory followed by the sequence number; also re-arms the tile counters.
+__device__ __forceinline__ void finalize_emit(const FinArgs &f, const double *tot) {
     if (threadIdx.x < 8) f.tile_ctr[threadIdx.x * 16] = 0;     // ready for the next k_nn_scan
     if (threadIdx.x == 0) {
         if (f.kind != PCR_ICP) {
@@ -420,7 +383,48 @@ __device__ __forceinline__ void finalize_body(const FinArgs &f) {
     }
 }
 
-__global__ void __launch_bounds__(1024) k_finalize(const FinArgs f) { finalize_body<false, 1024>(f); }
+// Stand-alone fold (variant 0, and PCR_FUSE_FINALIZE=0): ONE block of NT threads.
+template <int NT>
+__device__ __forceinline__ void finalize_body(const FinArgs &f) {
+    __shared__ double part[32][33];
+    __shared__ double tot[32];
+    constexpr int RPT = 32 / (NT / 32);                        // row-groups per thread: 1 (1024 threads) or 4 (256)
+    const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;     // 32 row-groups x 32 components
+    // RPT x 8 independent loads in flight per thread (a single dependent chain is pure latency)
+    double s8[RPT][8];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s8[q][u] = 0.0;
+    for (int b00 = 0; b00 < f.nblocks; b00 += 256) {
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b00 + r0 + q * (NT / 32) + 32 * u;
+                double v = 0.0;
+                if (b < f.nblocks) {
+                    const double *src = &f.partials[(size_t)b * 32 + c];
+                    v = *src;
+                }
+                s8[q][u] += v;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < RPT; ++q)
+        part[r0 + q * (NT / 32)][c] = ((s8[q][0] + s8[q][1]) + (s8[q][2] + s8[q][3])) + ((s8[q][4] + s8[q][5]) + (s8[q][6] + s8[q][7]));
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double t = 0.0;
+        for (int k = 0; k < 32; ++k) t += part[k][threadIdx.x];
+        tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+    finalize_emit(f, tot);
+}
+
+__global__ void __launch_bounds__(1024) k_finalize(const FinArgs f) { finalize_body<1024>(f); }
 
 template <int KIND>
 __global__ void __launch_bounds__(256) k_reduce(const LinArgs a) {
@@ -439,9 +443,13 @@ __global__ void __launch_bounds__(256) k_reduce(const LinArgs a) {
     block_store_partials(acc, a.partials);
 }
 
-// Small grids (<= 256 blocks): the block that takes the last ticket folds the partials itself, which
-// saves the separate k_finalize launch (~10 us + a launch gap of a ~75 us pass at 100 k points).  With
-// 1024 blocks the serialised tickets cost more than that launch (measured), hence two variants.
+// k_reduce with the fold of the partials inside (no separate k_finalize launch: ~10 us and a launch
+// gap per pass).  Any grid that is a multiple of 8 blocks; two levels of tickets.  Blocks g, g+8, g+16, ... form group g (the
+// blocks the dispatcher places on XCD g, so a group's traffic stays in one L2 -- a locality
+// assumption only, every cross-block access is coherent at agent scope).  The block that takes a
+// group's last ticket folds the group's partials into row nblocks+g; the group leader that takes the
+// last of the 8 second-level tickets folds those rows and emits.  8 x (nblocks/8) + 8 serialised
+// atomics instead of nblocks, and no separate k_finalize launch.
 template <int KIND>
 __global__ void __launch_bounds__(256) k_reduce_finalize(const LinArgs a, const FinArgs f) {
     double acc[32];
@@ -457,17 +465,64 @@ __global__ void __launch_bounds__(256) k_reduce_finalize(const LinArgs a, const 
         accumulate<KIND>(acc, a, j, x, y, z, tx, ty, tz);
     }
     block_store_partials<true>(acc, a.partials);
-    __shared__ int last;
+
+    __shared__ int role;
+    __shared__ double part[8][33];
+    __shared__ double tot[32];
+    const int g = (int)(blockIdx.x & 7), per = f.nblocks >> 3;
+    uint32_t *ctr1 = &f.tile_ctr[(8 + g) * 16], *ctr2 = &f.tile_ctr[16 * 16];
+    double *rows = const_cast<double *>(f.partials);
     if (threadIdx.x == 0) {
-        // the 32 partial stores above were issued by this wave: wait for their completion, then take a ticket
+        // the 32 partial stores were issued by this wave: wait for their completion, then take a ticket
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        const uint32_t t = __hip_atomic_fetch_add(&f.tile_ctr[8 * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = t == (uint32_t)(f.nblocks - 1);
+        const uint32_t t = __hip_atomic_fetch_add(ctr1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        role = t == (uint32_t)(per - 1);
     }
     __syncthreads();
-    if (!last) return;
-    if (threadIdx.x == 0) __hip_atomic_store(&f.tile_ctr[8 * 16], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    finalize_body<true, 256>(f);
+    if (!role) return;
+
+    // ---- group leader: rows g + 8 i, i = 0 .. per-1, in a fixed order; 16 loads in flight per thread
+    const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+    double s16[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s16[u] = 0.0;
+    for (int i0 = 0; i0 < per; i0 += 128) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = i0 + r0 + 8 * u;
+            double v = 0.0;
+            if (i < per) v = __hip_atomic_load(&rows[(size_t)(g + 8 * i) * 32 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s16[u] += v;
+        }
+    }
+    part[r0][c] = (((s16[0] + s16[1]) + (s16[2] + s16[3])) + ((s16[4] + s16[5]) + (s16[6] + s16[7]))) +
+                  (((s16[8] + s16[9]) + (s16[10] + s16[11])) + ((s16[12] + s16[13]) + (s16[14] + s16[15])));
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int k = threadIdx.x;
+        const double t = ((part[0][k] + part[1][k]) + (part[2][k] + part[3][k])) + ((part[4][k] + part[5][k]) + (part[6][k] + part[7][k]));
+        __hip_atomic_store(&rows[(size_t)(f.nblocks + g) * 32 + k], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(ctr1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // re-armed for the next pass
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        const uint32_t t2 = __hip_atomic_fetch_add(ctr2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        role = t2 == 7u;
+    }
+    __syncthreads();
+    if (!role) return;
+
+    // ---- the last group leader: the 8 group rows, in order
+    if (threadIdx.x == 0) __hip_atomic_store(ctr2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 32) {
+        double v[8];
+#pragma unroll
+        for (int gg = 0; gg < 8; ++gg)
+            v[gg] = __hip_atomic_load(&rows[(size_t)(f.nblocks + gg) * 32 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tot[threadIdx.x] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    __syncthreads();
+    finalize_emit(f, tot);
 }
 
 // after the RCCL all-reduce: hand the 29 doubles to the host the same zero-copy way k_finalize does
@@ -505,8 +560,8 @@ pcr_status pcr_ensure_scratch(pcr_context *ctx, int64_t n_points) {
         HIP_TRY(hipHostMalloc(&ctx->h_out, sizeof(double) * 40, hipHostMallocMapped | hipHostMallocCoherent));
         memset(ctx->h_out, 0, sizeof(double) * 40);
         HIP_TRY(hipHostGetDevicePointer((void **)&ctx->h_out_dev, ctx->h_out, 0));
-        HIP_TRY(hipMalloc(&ctx->d_tile_ctr, sizeof(uint32_t) * 9 * 16));       // 8 tile counters + 1 ticket
-        HIP_TRY(hipMemsetAsync(ctx->d_tile_ctr, 0, sizeof(uint32_t) * 9 * 16, ctx->stream));
+        HIP_TRY(hipMalloc(&ctx->d_tile_ctr, sizeof(uint32_t) * 17 * 16));      // 8 tile counters + 8 + 1 tickets
+        HIP_TRY(hipMemsetAsync(ctx->d_tile_ctr, 0, sizeof(uint32_t) * 17 * 16, ctx->stream));
         for (int v = 0; v < 2; ++v) {
             int nb = 0;
             hipError_t e = v == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<0>, 256, 0)
@@ -573,9 +628,7 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
     a.nn_j = ctx->d_nn_j; a.tile_ctr = ctx->d_tile_ctr;
 
     if (ctx->variant == 1 && a.nblocks > ctx->num_cu * 4) a.nblocks = ctx->num_cu * 4;   // k_reduce streams: 4 blocks/CU
-    // small scans: at most 256 reduce blocks, the last of which also folds the partials (k_reduce_finalize)
-    const bool fused_fin = ctx->variant == 1 && ctx->fuse_finalize && a.nblocks <= 512;
-    if (fused_fin && a.nblocks > 256) a.nblocks = 256;
+    const bool fused_fin = ctx->variant == 1 && ctx->fuse_finalize;       // k_reduce_finalize instead of k_reduce + k_finalize
     ProfEvent ev;
     const dim3 grid(a.nblocks), block(256);
 

@@ -104,7 +104,7 @@ struct pcr_context {
     uint32_t *d_nn_j = nullptr;
     int64_t nn_cap = 0;
     int variant = 0;
-    bool fuse_finalize = true;   // small reduce grids fold their partials in the last block (PCR_FUSE_FINALIZE=0 disables)
+    bool fuse_finalize = true;   // k_reduce_finalize (PCR_FUSE_FINALIZE=0: k_reduce + k_finalize)
     uint32_t *d_tile_ctr = nullptr;     // per-XCD dynamic tile counters of k_nn_scan
     int nn_blocks_per_cu[2] = {4, 4};   // resident 256-thread blocks per CU of k_nn_scan<0/1>
     // profiling
