@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Soak test of the pass pipeline: random scan sizes / kinds / poses for a fixed wall time; every pass
+is evaluated twice and must be bit-identical (catches lost tickets, stale partials, counter races)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from point_cloud_registration_amd import _capi
+from point_cloud_registration_amd.synthetic import street, perturbed_scan, make_T
+
+seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(0)
+target = street(400_000, seed=3)
+ctx = _capi.get_context(0)
+tp = _capi.Target.points(ctx, target); tp.estimate_normals(10, want=False)
+tv = _capi.Target.voxels(ctx, target, 1.0, 10)
+full, _ = perturbed_scan(target, None, seed=4)
+t0 = time.time(); passes = 0; scans = 0
+while time.time() - t0 < seconds:
+    n = int(rng.choice([1, 7, 63, 64, 65, 500, 2047, 2048, 2049, 30_000, 131_072, 131_073, 250_000, int(rng.integers(1, 400_000))]))
+    sc = _capi.Scan(ctx, full[rng.permutation(len(full))[:n]].copy()); scans += 1
+    for _ in range(40):
+        kind = int(rng.integers(0, 4))
+        T = make_T(rng.normal(0, 0.01, 3), rng.normal(0, 0.05, 3))
+        tgt = tp if kind < 2 else tv
+        a = _capi.linearize(tgt, sc, kind, T, 2.0)
+        b = _capi.linearize(tgt, sc, kind, T, 2.0)
+        if not np.array_equal(a, b) or not np.isfinite(a).all() or a[28] > n:
+            print("MISMATCH", n, kind, a[:3], b[:3], a[28], b[28]); sys.exit(1)
+        passes += 2
+    sc.close()
+print(f"soak ok: {passes} passes over {scans} scans in {time.time() - t0:.1f} s")
