@@ -55,7 +55,11 @@ enum {
 /* compat flags */
 enum {
     PCR_FLAG_ICP_RR_QUIRK = 1u,   /* reproduce icp.py:53-54: g[3:] = sum p x (R r) (quirk Q1); default */
-    PCR_FLAG_NO_SCAN_SORT = 2u    /* pcr_scan_create: keep the caller's point order on the device */
+    PCR_FLAG_NO_SCAN_SORT = 2u,   /* pcr_scan_create: keep the caller's point order on the device */
+    PCR_FLAG_LOCAL_ONLY = 4u,     /* pcr_linearize / pcr_align: this rank's sums only, no all-reduce even when a
+                                     communicator is attached to the context (the collective is a per-call decision) */
+    PCR_FLAG_HOST_LOOP = 8u       /* pcr_align: host-driven loop (one pcr_linearize + host solve per iteration)
+                                     instead of the device-resident one; same arithmetic, for A/B checks */
 };
 
 typedef struct pcr_context pcr_context;
@@ -76,7 +80,9 @@ PCR_API pcr_status pcr_context_synchronize(pcr_context *ctx);
  * No reference counterpart (the reference is single-process).  Rank 0 obtains an id with
  * pcr_comm_unique_id and distributes the 128 bytes out of band (bench.py uses
  * torch.distributed); every rank then calls pcr_comm_init.  After that pcr_linearize /
- * pcr_align return the SUM over all ranks' scan shards.                                  */
+ * pcr_align return the SUM over all ranks' scan shards, unless the call carries
+ * PCR_FLAG_LOCAL_ONLY (no collective is issued then; every rank of the communicator must
+ * make the same choice for a given call).                                                */
 PCR_API pcr_status pcr_comm_unique_id(void *id128);
 PCR_API pcr_status pcr_comm_init(pcr_context *ctx, const void *id128, int nranks, int rank);
 PCR_API pcr_status pcr_comm_destroy(pcr_context *ctx);
@@ -140,6 +146,9 @@ PCR_API pcr_status pcr_linearize(pcr_target *t, pcr_scan *s, int kind, const dou
 /* Registration.align (registration.py:71-113) run entirely behind the boundary: up to
  * max_iter x { pcr_linearize, dx = -solve(H, g), stop if |dx| < tol (before the update,
  * quirk Q4), T <- plus(T, dx) (math_tools.py:101-108, first-order expSO3 branch, quirk Q3) }.
+ * The loop is device-resident: the pose stays in HBM, the 6x6 solve and the update run in the
+ * last block of the reduce kernel, iterations are enqueued back to back and the host reads one
+ * result (PCR_FLAG_HOST_LOOP selects the host-driven form of the same arithmetic).
  * trace_or_null receives up to max_iter rows of 16 (T before the step) + 29 doubles.
  * Returns PCR_ERR_SINGULAR where numpy.linalg.solve would raise LinAlgError (quirk Q7).     */
 PCR_API pcr_status pcr_align(pcr_target *t, pcr_scan *s, int kind, const double T_init[16],
@@ -170,9 +179,18 @@ PCR_API pcr_status pcr_target_index_info(pcr_target *t, double *cell, int64_t di
  * same with each wave's maximum charged to all 64 lanes (the cost under divergence); out[8..10] =
  * wave wall-clock cycles summed over waves: prologue (load, transform, cell), ring 0, outer rings   */
 PCR_API pcr_status pcr_nn_counters(pcr_target *t, pcr_scan *s, const double T[16], double max_dist, double out[11]);
-/* select the hot-path variant: 0 = fused transform+NN+reduce kernel (default), 1 = NN kernel
- * writing correspondences to HBM followed by a reduce kernel                               */
+/* select the hot-path variant: 1 (default) = NN kernel writing correspondences to HBM followed by
+ * a reduce kernel that also folds the partial sums; 0 = one fused transform+NN+reduce kernel +
+ * a fold kernel (kept for A/B measurements: measured slower on MI355X)                     */
 PCR_API pcr_status pcr_set_variant(pcr_context *ctx, int variant);
+PCR_API pcr_status pcr_get_variant(pcr_context *ctx, int *variant);
+/* NN search mode of variant 1: 0 = plain ring search, 1 = start every search from the scan
+ * point's match of the previous pass against the same target (an exact upper bound)       */
+PCR_API pcr_status pcr_set_nn_mode(pcr_context *ctx, int mode);
+/* variant 1: 1 (default) = the reduce kernel folds the per-block partial sums itself
+ * (k_reduce_finalize); 0 = separate fold kernel                                             */
+PCR_API pcr_status pcr_set_fuse_finalize(pcr_context *ctx, int on);
+PCR_API pcr_status pcr_get_pipeline(pcr_context *ctx, int *variant, int *fuse_finalize, int *nn_mode);
 
 #ifdef __cplusplus
 }

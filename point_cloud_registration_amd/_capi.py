@@ -19,6 +19,8 @@ PCR_ERR_INVALID, PCR_ERR_HIP, PCR_ERR_NO_TARGET, PCR_ERR_COMM, PCR_ERR_SINGULAR,
 ICP, PLANE, VPLANE, NDT = 0, 1, 2, 3
 FLAG_ICP_RR_QUIRK = 1
 FLAG_NO_SCAN_SORT = 2
+FLAG_LOCAL_ONLY = 4          # no all-reduce even when the context has a communicator
+FLAG_HOST_LOOP = 8           # pcr_align: host-driven loop instead of the device-resident one
 K_LINEARIZE, K_FINALIZE, K_NN, K_REDUCE, K_ALLREDUCE, K_COUNT = 0, 1, 2, 3, 4, 5
 KERNEL_NAMES = ("linearize", "finalize", "nn", "reduce", "allreduce")
 
@@ -69,6 +71,10 @@ PROTOTYPES = {
     "pcr_profile_read": (C.c_int, [_vp, _i64p, _f64p]),
     "pcr_target_index_info": (C.c_int, [_vp, C.POINTER(C.c_double), _i64p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pcr_set_variant": (C.c_int, [_vp, C.c_int]),
+    "pcr_get_variant": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "pcr_set_nn_mode": (C.c_int, [_vp, C.c_int]),
+    "pcr_set_fuse_finalize": (C.c_int, [_vp, C.c_int]),
+    "pcr_get_pipeline": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pcr_nn_counters": (C.c_int, [_vp, _vp, _f64p, C.c_double, _f64p]),
 }
 
@@ -181,6 +187,44 @@ class Context:
 
     def set_variant(self, v):
         check(lib().pcr_set_variant(self.handle, int(v)))
+
+    def get_variant(self):
+        v = C.c_int(0)
+        check(lib().pcr_get_variant(self.handle, C.byref(v)))
+        return v.value
+
+    def set_nn_mode(self, m):
+        check(lib().pcr_set_nn_mode(self.handle, int(m)))
+
+    def set_fuse_finalize(self, on):
+        check(lib().pcr_set_fuse_finalize(self.handle, int(bool(on))))
+
+    def get_pipeline(self):
+        v, f, m = C.c_int(0), C.c_int(0), C.c_int(0)
+        check(lib().pcr_get_pipeline(self.handle, C.byref(v), C.byref(f), C.byref(m)))
+        return {"variant": v.value, "fuse_finalize": f.value, "nn_mode": m.value}
+
+    def pipeline(self, variant=None, fuse_finalize=None, nn_mode=None):
+        """Context manager: select a kernel pipeline for the enclosed calls and RESTORE the previous
+        selection afterwards (the context is process-wide)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _cm():
+            prev = self.get_pipeline()
+            try:
+                if variant is not None:
+                    self.set_variant(variant)
+                if fuse_finalize is not None:
+                    self.set_fuse_finalize(fuse_finalize)
+                if nn_mode is not None:
+                    self.set_nn_mode(nn_mode)
+                yield self
+            finally:
+                self.set_variant(prev["variant"])
+                self.set_fuse_finalize(prev["fuse_finalize"])
+                self.set_nn_mode(prev["nn_mode"])
+        return _cm()
 
     # -- RCCL
     def comm_init(self, uid, nranks, rank):

@@ -7,6 +7,7 @@
 
 #include <string>
 
+#include "gn_math.h"
 #include "pcr_internal.h"
 
 // ---- errors ---------------------------------------------------------------------------------
@@ -54,6 +55,8 @@ extern "C" pcr_status pcr_context_create(int device, pcr_context **out) {
     ctx->variant = 1;      // measured on MI355X: NN kernel + reduce kernel beats the fused kernel (occupancy)
     const char *v = getenv("PCR_VARIANT");
     if (v) ctx->variant = atoi(v) == 0 ? 0 : 1;
+    const char *nm = getenv("PCR_NN_MODE");
+    if (nm && *nm) ctx->nn_mode = atoi(nm);
     const char *ff = getenv("PCR_FUSE_FINALIZE");
     if (ff && *ff) ctx->fuse_finalize = atoi(ff) != 0;
     *out = ctx;
@@ -70,7 +73,8 @@ extern "C" pcr_status pcr_context_destroy(pcr_context *ctx) {
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->h_out) (void)hipHostFree(ctx->h_out);
-    if (ctx->d_nn_j) (void)hipFree(ctx->d_nn_j);
+    if (ctx->d_pose) (void)hipFree(ctx->d_pose);
+    if (ctx->d_trace) (void)hipFree(ctx->d_trace);
     if (ctx->d_tile_ctr) (void)hipFree(ctx->d_tile_ctr);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -93,6 +97,33 @@ extern "C" pcr_status pcr_set_variant(pcr_context *ctx, int variant) {
     PCR_REQUIRE(ctx, "ctx is NULL");
     PCR_REQUIRE(variant == 0 || variant == 1, "variant must be 0 or 1");
     ctx->variant = variant;
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_get_variant(pcr_context *ctx, int *variant) {
+    PCR_REQUIRE(ctx && variant, "NULL argument");
+    *variant = ctx->variant;
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_set_fuse_finalize(pcr_context *ctx, int on) {
+    PCR_REQUIRE(ctx, "ctx is NULL");
+    ctx->fuse_finalize = on != 0;
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_get_pipeline(pcr_context *ctx, int *variant, int *fuse_finalize, int *nn_mode) {
+    PCR_REQUIRE(ctx, "ctx is NULL");
+    if (variant) *variant = ctx->variant;
+    if (fuse_finalize) *fuse_finalize = ctx->fuse_finalize ? 1 : 0;
+    if (nn_mode) *nn_mode = ctx->nn_mode;
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_set_nn_mode(pcr_context *ctx, int mode) {
+    PCR_REQUIRE(ctx, "ctx is NULL");
+    PCR_REQUIRE(mode >= 0 && mode <= 2, "nn mode must be 0, 1 or 2");
+    ctx->nn_mode = mode;
     return PCR_OK;
 }
 
@@ -167,7 +198,7 @@ static pcr_status upload(pcr_context *ctx, const T *host, size_t count, T **dev)
 
 static void target_free(pcr_target *t) {
     if (!t) return;
-    void *ptrs[] = {t->cell_start, t->cell_seed, t->pts, t->normals, t->means, t->vnorm, t->vicov,
+    void *ptrs[] = {t->cell_start, t->cell_seed, t->pts, t->pn, t->means, t->vnorm, t->vicov,
                     t->st_mean, t->st_cov, t->st_norm, t->st_icov, t->st_counts, t->st_keys};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete t;
@@ -177,12 +208,12 @@ static void target_free(pcr_target *t) {
 static pcr_status points_create_common(pcr_context *ctx, const float *d_xyz, int64_t n, const float *d_normals,
                                        float cell_hint, pcr_target **out) {
     pcr_target *t = new pcr_target();
-    t->ctx = ctx; t->is_voxel = 0; t->n = n;
+    t->ctx = ctx; t->is_voxel = 0; t->n = n; t->serial = ctx->next_serial++;
     pcr_status s = pcr_build_point_grid(ctx, d_xyz, n, cell_hint, t);
     if (s == PCR_OK && d_normals) {
-        hipError_t e = hipMalloc(&t->normals, sizeof(float4) * (size_t)(n ? n : 1));
+        hipError_t e = hipMalloc(&t->pn, sizeof(PtN) * (size_t)(n ? n : 1));
         if (e != hipSuccess) { pcr_set_error("hipMalloc normals: %s", hipGetErrorString(e)); s = PCR_ERR_HIP; }
-        else s = pcr_permute_rows_f32(ctx, d_normals, n, 3, t->pts, t->normals);
+        else s = pcr_permute_normals(ctx, d_normals, n, t->pts, t->pn);
         if (s == PCR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s = PCR_ERR_HIP;
     }
     if (s != PCR_OK) { target_free(t); return s; }
@@ -221,31 +252,30 @@ extern "C" pcr_status pcr_target_set_normals(pcr_target *t, const float *normals
     HIP_TRY(hipSetDevice(ctx->device));
     DevBuf<float> d_nrm;
     PCR_TRY(upload<float>(ctx, normals, (size_t)t->n * 3, &d_nrm.p));
-    if (!t->normals) HIP_TRY(hipMalloc(&t->normals, sizeof(float4) * (size_t)(t->n ? t->n : 1)));
-    PCR_TRY(pcr_permute_rows_f32(ctx, d_nrm.p, t->n, 3, t->pts, t->normals));
+    if (!t->pn) HIP_TRY(hipMalloc(&t->pn, sizeof(PtN) * (size_t)(t->n ? t->n : 1)));
+    PCR_TRY(pcr_permute_normals(ctx, d_nrm.p, t->n, t->pts, t->pn));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PCR_OK;
 }
 
-__global__ void __launch_bounds__(256) k_unpermute_normals(const float4 *__restrict__ nrm, const PtF *__restrict__ pts,
-                                                           int64_t n, float *out) {
+__global__ void __launch_bounds__(256) k_unpermute_normals(const PtN *__restrict__ pn, int64_t n, float *out) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
-    const size_t i = __float_as_uint(pts[j].w);
-    const float4 v = nrm[j];
-    out[3 * i] = v.x; out[3 * i + 1] = v.y; out[3 * i + 2] = v.z;
+    const PtN v = pn[j];
+    const size_t i = v.orig;
+    out[3 * i] = v.nx; out[3 * i + 1] = v.ny; out[3 * i + 2] = v.nz;
 }
 
 extern "C" pcr_status pcr_target_get_normals(pcr_target *t, float *normals_out) {
     PCR_REQUIRE(t && normals_out, "NULL argument");
-    if (t->is_voxel || !t->normals) { pcr_set_error("target has no per-point normals"); return PCR_ERR_NO_TARGET; }
+    if (t->is_voxel || !t->pn) { pcr_set_error("target has no per-point normals"); return PCR_ERR_NO_TARGET; }
     pcr_context *ctx = t->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     if (t->n == 0) return PCR_OK;
     DevBuf<float> d_out;
     HIP_TRY(d_out.alloc(3 * (size_t)t->n));
     hipLaunchKernelGGL(k_unpermute_normals, dim3((unsigned)((t->n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       t->normals, t->pts, t->n, d_out.p);
+                       t->pn, t->n, d_out.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(normals_out, d_out.p, sizeof(float) * 3 * (size_t)t->n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -281,7 +311,7 @@ extern "C" pcr_status pcr_target_voxels_create_from_stats(pcr_context *ctx, cons
     PCR_REQUIRE(voxel_size > 0, "voxel_size must be positive");
     HIP_TRY(hipSetDevice(ctx->device));
     pcr_target *t = new pcr_target();
-    t->ctx = ctx; t->is_voxel = 1; t->n = n_v;
+    t->ctx = ctx; t->is_voxel = 1; t->n = n_v; t->serial = ctx->next_serial++;
     pcr_status s = upload<double>(ctx, mean, (size_t)n_v * 3, &t->st_mean);
     if (s == PCR_OK && norm_or_null) s = upload<double>(ctx, norm_or_null, (size_t)n_v * 3, &t->st_norm);
     if (s == PCR_OK && icov_or_null) s = upload<double>(ctx, icov_or_null, (size_t)n_v * 9, &t->st_icov);
@@ -374,6 +404,7 @@ extern "C" pcr_status pcr_scan_destroy(pcr_scan *s) {
     if (s->x) (void)hipFree(s->x);
     if (s->y) (void)hipFree(s->y);
     if (s->z) (void)hipFree(s->z);
+    if (s->nn_j) (void)hipFree(s->nn_j);
     delete s;
     return PCR_OK;
 }
@@ -386,67 +417,11 @@ extern "C" pcr_status pcr_linearize(pcr_target *t, pcr_scan *s, int kind, const 
 }
 
 // ---- Gauss-Newton driver behind the boundary (registration.py:71-113) -------------------------
-// numpy.linalg.solve: LU with partial pivoting, exact-zero pivot = singular (quirk Q7)
-static int solve6(const double H[36], const double g[6], double x[6]) {
-    double A[6][7];
-    for (int i = 0; i < 6; ++i) { for (int j = 0; j < 6; ++j) A[i][j] = H[6 * i + j]; A[i][6] = g[i]; }
-    for (int c = 0; c < 6; ++c) {
-        int piv = c;
-        for (int r = c + 1; r < 6; ++r) if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
-        if (A[piv][c] == 0.0) return 1;
-        if (piv != c) for (int j = 0; j < 7; ++j) { const double tmp = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = tmp; }
-        for (int r = c + 1; r < 6; ++r) {
-            const double f = A[r][c] / A[c][c];
-            for (int j = c; j < 7; ++j) A[r][j] -= f * A[c][j];
-        }
-    }
-    for (int i = 5; i >= 0; --i) {
-        double v = A[i][6];
-        for (int j = i + 1; j < 6; ++j) v -= A[i][j] * x[j];
-        x[i] = v / A[i][i];
-    }
-    return 0;
-}
-
-// math_tools.py:80-98: first-order I + skew(w) when w.w <= 1e-5 (quirk Q3), Rodrigues otherwise
-static void exp_so3(const double w[3], double R[9]) {
-    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
-    const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
-    if (th2 <= 1e-5) {
-        for (int i = 0; i < 9; ++i) R[i] = W[i];
-    } else {
-        const double th = sqrt(th2), sn = sin(th), omc = 1.0 - cos(th);
-        double K[9];
-        for (int i = 0; i < 9; ++i) K[i] = W[i] / th;
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) {
-                double kk = 0;
-                for (int k = 0; k < 3; ++k) kk += K[3 * i + k] * K[3 * k + j];
-                R[3 * i + j] = sn * K[3 * i + j] + omc * kk;
-            }
-    }
-    R[0] += 1; R[4] += 1; R[8] += 1;
-}
-
-// math_tools.py:101-108: T <- T @ [exp(w), v; 0 1] (quirk Q2)
-static void se3_plus(double T[16], const double dx[6]) {
-    double dR[9];
-    exp_so3(dx + 3, dR);
-    const double D[16] = {dR[0], dR[1], dR[2], dx[0], dR[3], dR[4], dR[5], dx[1], dR[6], dR[7], dR[8], dx[2], 0, 0, 0, 1};
-    double r[16];
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) {
-            double v = 0;
-            for (int k = 0; k < 4; ++k) v += T[4 * i + k] * D[4 * k + j];
-            r[4 * i + j] = v;
-        }
-    memcpy(T, r, sizeof r);
-}
-
-extern "C" pcr_status pcr_align(pcr_target *t, pcr_scan *s, int kind, const double T_init[16], int max_iter, double tol,
-                                double max_dist, unsigned flags, double T_out[16], int *iterations,
-                                double *trace_or_null) {
-    PCR_REQUIRE(t && s && T_init && T_out, "NULL argument");
+// Default: the device-resident loop (kernels.hip: pcr_run_align).  PCR_FLAG_HOST_LOOP keeps the
+// host-driven form (one pcr_linearize + host solve per iteration), the same arithmetic from gn_math.h.
+static pcr_status align_host_loop(pcr_target *t, pcr_scan *s, int kind, const double T_init[16], int max_iter, double tol,
+                                  double max_dist, unsigned flags, double T_out[16], int *iterations,
+                                  double *trace_or_null) {
     double T[16];
     memcpy(T, T_init, sizeof T);
     int it = 0;
@@ -457,24 +432,28 @@ extern "C" pcr_status pcr_align(pcr_target *t, pcr_scan *s, int kind, const doub
             memcpy(trace_or_null + (size_t)it * 45, T, 16 * sizeof(double));
             memcpy(trace_or_null + (size_t)it * 45 + 16, o, 29 * sizeof(double));
         }
-        double H[36], g[6], dx[6];
-        int p = 0;
-        for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) { H[6 * i + j] = o[p]; H[6 * j + i] = o[p]; ++p; }
-        for (int i = 0; i < 6; ++i) g[i] = o[21 + i];
-        if (solve6(H, g, dx)) {
+        double A[6][7];
+        const int r = gn_step(A, o, tol, T);
+        if (r == 2) {
             pcr_set_error("Singular matrix (correspondences: %.0f)", o[28]);
             if (iterations) *iterations = it + 1;
             memcpy(T_out, T, sizeof T);
             return PCR_ERR_SINGULAR;
         }
-        double nrm = 0;
-        for (int i = 0; i < 6; ++i) { dx[i] = -dx[i]; nrm += dx[i] * dx[i]; }
-        if (sqrt(nrm) < tol) { ++it; break; }     // registration.py:106-108: test precedes the update (Q4)
-        se3_plus(T, dx);
+        if (r == 1) { ++it; break; }              // registration.py:106-108: test precedes the update (Q4)
     }
     if (iterations) *iterations = it;
     memcpy(T_out, T, sizeof T);
     return PCR_OK;
+}
+
+extern "C" pcr_status pcr_align(pcr_target *t, pcr_scan *s, int kind, const double T_init[16], int max_iter, double tol,
+                                double max_dist, unsigned flags, double T_out[16], int *iterations,
+                                double *trace_or_null) {
+    PCR_REQUIRE(t && s && T_init && T_out, "NULL argument");
+    if (flags & PCR_FLAG_HOST_LOOP)
+        return align_host_loop(t, s, kind, T_init, max_iter, tol, max_dist, flags, T_out, iterations, trace_or_null);
+    return pcr_run_align(t, s, kind, T_init, max_iter, tol, max_dist, flags, T_out, iterations, trace_or_null);
 }
 
 // ---- KD-tree seam ----------------------------------------------------------------------------

@@ -1,0 +1,84 @@
+// The O(1) tail of a Gauss-Newton iteration, shared by the host driver (api.hip) and the last block
+// of the reduce kernel (kernels.hip): dx = -solve(H, g), the |dx| < tol test, T <- plus(T, dx).
+// Reference: registration.py:103-111 (loop body), math_tools.py:80-108 (expSO3, plus).
+#pragma once
+
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define PCR_HD __host__ __device__
+#else
+#define PCR_HD
+#endif
+
+// numpy.linalg.solve: LU with partial pivoting, exact-zero pivot = singular (quirk Q7).
+// A is caller-provided 6 x 7 working storage (shared memory on the device: dynamic row indices).
+PCR_HD static inline int gn_solve6(double (*A)[7], const double H[36], const double g[6], double x[6]) {
+    for (int i = 0; i < 6; ++i) { for (int j = 0; j < 6; ++j) A[i][j] = H[6 * i + j]; A[i][6] = g[i]; }
+    for (int c = 0; c < 6; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 6; ++r) if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
+        if (A[piv][c] == 0.0) return 1;
+        if (piv != c) for (int j = 0; j < 7; ++j) { const double tmp = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = tmp; }
+        for (int r = c + 1; r < 6; ++r) {
+            const double f = A[r][c] / A[c][c];
+            for (int j = c; j < 7; ++j) A[r][j] -= f * A[c][j];
+        }
+    }
+    for (int i = 5; i >= 0; --i) {
+        double v = A[i][6];
+        for (int j = i + 1; j < 6; ++j) v -= A[i][j] * x[j];
+        x[i] = v / A[i][i];
+    }
+    return 0;
+}
+
+// math_tools.py:80-98: first-order I + skew(w) when w.w <= 1e-5 (quirk Q3), Rodrigues otherwise
+PCR_HD static inline void gn_exp_so3(const double w[3], double R[9]) {
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+    if (th2 <= 1e-5) {
+        for (int i = 0; i < 9; ++i) R[i] = W[i];
+    } else {
+        const double th = sqrt(th2), sn = sin(th), omc = 1.0 - cos(th);
+        double K[9];
+        for (int i = 0; i < 9; ++i) K[i] = W[i] / th;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double kk = 0;
+                for (int k = 0; k < 3; ++k) kk += K[3 * i + k] * K[3 * k + j];
+                R[3 * i + j] = sn * K[3 * i + j] + omc * kk;
+            }
+    }
+    R[0] += 1; R[4] += 1; R[8] += 1;
+}
+
+// math_tools.py:101-108: T <- T @ [exp(w), v; 0 1] (quirk Q2)
+PCR_HD static inline void gn_se3_plus(double T[16], const double dx[6]) {
+    double dR[9];
+    gn_exp_so3(dx + 3, dR);
+    const double D[16] = {dR[0], dR[1], dR[2], dx[0], dR[3], dR[4], dR[5], dx[1], dR[6], dR[7], dR[8], dx[2], 0, 0, 0, 1};
+    double r[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double v = 0;
+            for (int k = 0; k < 4; ++k) v += T[4 * i + k] * D[4 * k + j];
+            r[4 * i + j] = v;
+        }
+    for (int i = 0; i < 16; ++i) T[i] = r[i];
+}
+
+// One Gauss-Newton step from the 29 sums (include/pcr.h layout).  Returns 0 = stepped (T updated),
+// 1 = converged (|dx| < tol: the test precedes the update, quirk Q4; T unchanged), 2 = singular.
+PCR_HD static inline int gn_step(double (*A)[7], const double o[29], double tol, double T[16]) {
+    double H[36], g[6], dx[6];
+    int p = 0;
+    for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) { H[6 * i + j] = o[p]; H[6 * j + i] = o[p]; ++p; }
+    for (int i = 0; i < 6; ++i) g[i] = o[21 + i];
+    if (gn_solve6(A, H, g, dx)) return 2;
+    double nrm = 0;
+    for (int i = 0; i < 6; ++i) { dx[i] = -dx[i]; nrm += dx[i] * dx[i]; }
+    if (sqrt(nrm) < tol) return 1;
+    gn_se3_plus(T, dx);
+    return 0;
+}

@@ -10,6 +10,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <math.h>
+#include <cmath>
 
 #include "nn_device.h"
 
@@ -25,18 +26,24 @@ static inline float ord2f(unsigned u) {
     return f;
 }
 
-// box[0..2] = min (ordered-uint encoding), box[3..5] = max
+// box[0..2] = min (ordered-uint encoding), box[3..5] = max over the FINITE points; box[6] = number of
+// points with a NaN / inf coordinate (they are left out of the box: an inf would blow the grid up, a
+// NaN is invisible to fmin/fmax anyway)
 template <typename T>
 __global__ void __launch_bounds__(256) k_bbox(const T *__restrict__ xyz, int64_t n, unsigned *box) {
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    unsigned bad = 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const T v0 = xyz[3 * i], v1 = xyz[3 * i + 1], v2 = xyz[3 * i + 2];
+        const T v[3] = {v0, v1, v2};
+        const T big = (T)3.0e38;                                      // beyond float32 range counts as non-finite
+        if (!(fabs(v0) <= big && fabs(v1) <= big && fabs(v2) <= big)) { ++bad; continue; }
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             // round outward when narrowing float64 centroids
-            const T v = xyz[3 * i + a];
-            float fl = (float)v, fh = (float)v;
-            if ((T)fl > v) fl = nextafterf(fl, -INFINITY);
-            if ((T)fh < v) fh = nextafterf(fh, INFINITY);
+            float fl = (float)v[a], fh = (float)v[a];
+            if ((T)fl > v[a]) fl = nextafterf(fl, -INFINITY);
+            if ((T)fh < v[a]) fh = nextafterf(fh, INFINITY);
             lo[a] = fminf(lo[a], fl); hi[a] = fmaxf(hi[a], fh);
         }
     }
@@ -47,12 +54,15 @@ __global__ void __launch_bounds__(256) k_bbox(const T *__restrict__ xyz, int64_t
             hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
         }
     }
+    for (int off = 32; off >= 1; off >>= 1) bad += __shfl_xor(bad, off, 64);
     // one atomic per block and component (thousands of waves hammering six words serialise badly)
     __shared__ float slo[4][3], shi[4][3];
+    __shared__ unsigned sbad[4];
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) { slo[wave][a] = lo[a]; shi[wave][a] = hi[a]; }
+        sbad[wave] = bad;
     }
     __syncthreads();
     if (threadIdx.x < 3) {
@@ -62,26 +72,34 @@ __global__ void __launch_bounds__(256) k_bbox(const T *__restrict__ xyz, int64_t
         atomicMin(&box[a], f2ord(l));
         atomicMax(&box[3 + a], f2ord(h));
     }
+    if (threadIdx.x == 3) {
+        const unsigned b = sbad[0] + sbad[1] + sbad[2] + sbad[3];
+        if (b) atomicAdd(&box[6], b);
+    }
 }
 
+// lo / hi over the finite points (0 when there is none); *nonfinite = how many points were left out
 template <typename T>
-static pcr_status device_bbox(pcr_context *ctx, const T *d_xyz, int64_t n, float lo[3], float hi[3]) {
+static pcr_status device_bbox(pcr_context *ctx, const T *d_xyz, int64_t n, float lo[3], float hi[3],
+                              int64_t *nonfinite = nullptr) {
     DevBuf<unsigned> d_box;
-    HIP_TRY(d_box.alloc(6));
-    unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    HIP_TRY(d_box.alloc(7));
+    unsigned init[7] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u};
     HIP_TRY(hipMemcpyAsync(d_box, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
     if (n > 0) {
         int64_t nb = (n + 255) / 256;
         if (nb > 1024) nb = 1024;
         hipLaunchKernelGGL(k_bbox<T>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_xyz, n, d_box);
     }
-    unsigned h[6];
+    unsigned h[7];
     HIP_TRY(hipMemcpyAsync(h, d_box, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const bool any = n > 0 && (int64_t)h[6] < n;
     for (int a = 0; a < 3; ++a) {
-        lo[a] = n > 0 ? ord2f(h[a]) : 0.f;
-        hi[a] = n > 0 ? ord2f(h[3 + a]) : 0.f;
+        lo[a] = any ? ord2f(h[a]) : 0.f;
+        hi[a] = any ? ord2f(h[3 + a]) : 0.f;
     }
+    if (nonfinite) *nonfinite = (int64_t)h[6];
     return PCR_OK;
 }
 
@@ -201,6 +219,8 @@ template <typename Real>
 static bool make_geom(const float lo[3], const float hi[3], double h, Geom<Real> *g, double *ncells) {
     g->ox = (Real)lo[0]; g->oy = (Real)lo[1]; g->oz = (Real)lo[2];
     g->h = (Real)h; g->inv_h = (Real)(1.0 / h);
+    *ncells = INFINITY;
+    if (!(h > 0.0) || !std::isfinite(h)) return false;
     double dims[3];
     for (int a = 0; a < 3; ++a) dims[a] = floor(((double)hi[a] - (double)lo[a]) / h) + 2.0;
     *ncells = dims[0] * dims[1] * dims[2];
@@ -255,7 +275,15 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
     PCR_REQUIRE(n < ((int64_t)1 << 31), "at most 2^31-1 points per target");
     HIP_TRY(hipSetDevice(ctx->device));
     float lo[3], hi[3];
-    PCR_TRY(device_bbox<T>(ctx, d_xyz, n, lo, hi));
+    int64_t nonfinite = 0;
+    PCR_TRY(device_bbox<T>(ctx, d_xyz, n, lo, hi, &nonfinite));
+    if (nonfinite > 0) {
+        // A target point with a NaN / inf coordinate (common in raw PCD files) has no cell and can be nobody's
+        // nearest neighbour; the reference's KD-tree would return garbage or hang on it.  Refuse it here.
+        pcr_set_error("target has %lld point(s) with a non-finite coordinate; drop them first "
+                      "(e.g. xyz[np.isfinite(xyz).all(1)])", (long long)nonfinite);
+        return PCR_ERR_INVALID;
+    }
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const double max_cells = fmin(1.0e9, (double)free_b / 4.0 / 8.0);   // cell_start may take 1/8 of free HBM
@@ -270,7 +298,10 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
     bool capped = false;          // hit the memory cap: cannot shrink further
     for (int iter = 0; iter < 16; ++iter) {
         Geom<Real> g;
-        while (!make_geom<Real>(lo, hi, h, &g, &ncells) || ncells > max_cells) { h *= 2.0; capped = true; }
+        while (!make_geom<Real>(lo, hi, h, &g, &ncells) || ncells > max_cells) {
+            h *= 2.0; capped = true;
+            if (!std::isfinite(h) || h > 1.0e30) { pcr_set_error("cannot build a cell grid over this bounding box"); return PCR_ERR_INVALID; }
+        }
         HIP_TRY(d_counts.alloc((size_t)ncells + 1));
         HIP_TRY(hipMemsetAsync(d_counts.p, 0, sizeof(uint32_t) * ((size_t)ncells + 1), ctx->stream));
         if (n > 0)
@@ -358,6 +389,12 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
     return PCR_OK;
 }
 
+pcr_status pcr_count_nonfinite(pcr_context *ctx, const void *d_xyz, int is_f64, int64_t n, int64_t *count) {
+    float lo[3], hi[3];
+    if (is_f64) return device_bbox<double>(ctx, (const double *)d_xyz, n, lo, hi, count);
+    return device_bbox<float>(ctx, (const float *)d_xyz, n, lo, hi, count);
+}
+
 pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n, float cell_hint, pcr_target *t) {
     double h = cell_hint > 0 ? (double)cell_hint : 0.5;
     const char *env = getenv("PCR_GRID_CELL");
@@ -371,19 +408,22 @@ pcr_status pcr_build_centroid_grid(pcr_context *ctx, const double *d_mean, int64
 }
 
 // ---- row permutations into cell-sorted order -------------------------------------------------
-__global__ void __launch_bounds__(256) k_perm_f32(const float *__restrict__ in, int64_t n, int width,
-                                                  const PtF *__restrict__ pts, float4 *out) {
+__global__ void __launch_bounds__(256) k_perm_normals(const float *__restrict__ in, int64_t n,
+                                                      const PtF *__restrict__ pts, PtN *out) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
-    const size_t i = __float_as_uint(pts[j].w);
-    float4 v = make_float4(0, 0, 0, 0);
-    v.x = in[i * width]; v.y = in[i * width + 1]; v.z = in[i * width + 2];
-    out[j] = v;
+    const PtF p = pts[j];
+    const size_t i = __float_as_uint(p.w);
+    PtN r;
+    r.x = p.x; r.y = p.y; r.z = p.z; r.orig = (uint32_t)i;
+    r.nx = in[3 * i]; r.ny = in[3 * i + 1]; r.nz = in[3 * i + 2]; r.pad = 0;
+    out[j] = r;
 }
 
-pcr_status pcr_permute_rows_f32(pcr_context *ctx, const float *d_in, int64_t n, int width, const PtF *pts, float4 *out) {
+// caller-order (N,3) normals -> cell-sorted {point, normal} records
+pcr_status pcr_permute_normals(pcr_context *ctx, const float *d_in, int64_t n, const PtF *pts, PtN *out) {
     if (n == 0) return PCR_OK;
-    hipLaunchKernelGGL(k_perm_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_in, n, width, pts, out);
+    hipLaunchKernelGGL(k_perm_normals, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_in, n, pts, out);
     HIP_TRY(hipGetLastError());
     return PCR_OK;
 }

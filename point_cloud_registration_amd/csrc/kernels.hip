@@ -22,7 +22,14 @@
 // a halving butterfly (32 shuffles instead of 32 x 6), then across waves through LDS.
 #include <string.h>
 
+#include "gn_math.h"
 #include "nn_device.h"
+
+// what the kernels need of a pose: float32 copy for the point transform, float64 rotation for the Jacobians
+struct PoseK {
+    float r32[9], t32[3];
+    double R[9];
+};
 
 struct LinArgs {
     // scan
@@ -31,29 +38,55 @@ struct LinArgs {
     // point target
     Geom<float> gf;
     const PtF *pts;
-    const float4 *normals;
+    const PtN *pn;
     // voxel target
     Geom<double> gd;
     const PtD *means;
     const double *vnorm;
     const double *vicov;
     const uint32_t *cell_start;
-    // transform: float32 copy for the point transform, float64 rotation for the Jacobians
-    float r32[9], t32[3];
-    double R[9];
+    // pose: by value (pcr_linearize: the caller's T) or, when `pose` is set, read from HBM at kernel
+    // start (pcr_align: the device-resident Gauss-Newton loop; pose->done != 0 turns the launch into a no-op)
+    PoseK hp;
+    const PoseDev *pose;
     float md_f;        // gate, float32 compare (point targets)
     double md_d;       // gate, float64 compare (voxel targets)
     float bound2_f;    // search bound (squared), slightly above the gate
     double bound2_d;
     unsigned flags;
     int nblocks;
-    double *partials;  // [nblocks][32]
+    double *partials;  // [nblocks + 8][32]
     // variant 1: correspondences through HBM
     uint32_t *nn_j;
     uint32_t *tile_ctr;   // 8 per-XCD tile counters (64 B apart) for k_nn_scan's dynamic scheduling
 };
 
-__device__ __forceinline__ void xform(const LinArgs &a, float x, float y, float z, float &tx, float &ty, float &tz) {
+__device__ __forceinline__ float uniform_f32(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ double uniform_f64(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+// The pose of this launch, in scalar registers.  Returns false when the device-resident loop has
+// already finished (nothing to do).  Every block reads the pose before it contributes to the
+// reduction, and the pose is rewritten only by the block that folds the LAST contribution, so a
+// read never races with the update; across launches the kernel boundary orders them.
+template <bool NEED_R>
+__device__ __forceinline__ bool load_pose(const LinArgs &a, PoseK &P) {
+    if (a.pose == nullptr) { P = a.hp; return true; }
+    const PoseDev *p = a.pose;
+    if (__builtin_amdgcn_readfirstlane(p->done) != 0) return false;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) P.r32[i] = uniform_f32(p->r32[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) P.t32[i] = uniform_f32(p->t32[i]);
+    if (NEED_R) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) P.R[i] = uniform_f64(p->R[i]);
+    }
+    return true;
+}
+
+__device__ __forceinline__ void xform(const PoseK &a, float x, float y, float z, float &tx, float &ty, float &tz) {
     // ((R00*x + R01*y) + R02*z) + t0, float32, no contraction: oracle orc_transform
     tx = ((a.r32[0] * x + a.r32[1] * y) + a.r32[2] * z) + a.t32[0];
     ty = ((a.r32[3] * x + a.r32[4] * y) + a.r32[5] * z) + a.t32[1];
@@ -77,7 +110,7 @@ __device__ __forceinline__ void acc_rank1(double *acc, const double J[6], double
     acc[28] += 1.0;
 }
 
-__device__ __forceinline__ void acc_plane(double *acc, const LinArgs &a, double x, double y, double z,
+__device__ __forceinline__ void acc_plane(double *acc, const PoseK &a, double x, double y, double z,
                                           double n0, double n1, double n2, double d0, double d1, double d2) {
     const double r = (n0 * d0 + n1 * d1) + n2 * d2;                          // plane_icp.py:49
     const double ra = a.R[0] * n0 + a.R[3] * n1 + a.R[6] * n2;               // R^T n, plane_icp.py:51
@@ -87,7 +120,7 @@ __device__ __forceinline__ void acc_plane(double *acc, const LinArgs &a, double 
     acc_rank1(acc, J, r);
 }
 
-__device__ __forceinline__ void acc_icp(double *acc, const LinArgs &a, double x, double y, double z,
+__device__ __forceinline__ void acc_icp(double *acc, const PoseK &a, unsigned flags, double x, double y, double z,
                                         double r0, double r1, double r2) {
     acc[0] += 1.0;
     acc[1] += x; acc[2] += y; acc[3] += z;
@@ -95,7 +128,7 @@ __device__ __forceinline__ void acc_icp(double *acc, const LinArgs &a, double x,
     acc[7] = fma(y, y, acc[7]); acc[8] = fma(y, z, acc[8]); acc[9] = fma(z, z, acc[9]);
     acc[10] += r0; acc[11] += r1; acc[12] += r2;
     double v0, v1, v2;
-    if (a.flags & PCR_FLAG_ICP_RR_QUIRK) {                                   // quirk Q1, icp.py:53-54
+    if (flags & PCR_FLAG_ICP_RR_QUIRK) {                                     // quirk Q1, icp.py:53-54
         v0 = a.R[0] * r0 + a.R[1] * r1 + a.R[2] * r2;
         v1 = a.R[3] * r0 + a.R[4] * r1 + a.R[5] * r2;
         v2 = a.R[6] * r0 + a.R[7] * r1 + a.R[8] * r2;
@@ -108,7 +141,7 @@ __device__ __forceinline__ void acc_icp(double *acc, const LinArgs &a, double x,
     acc[16] += r0 * r0 + r1 * r1 + r2 * r2;
 }
 
-__device__ __forceinline__ void acc_ndt(double *acc, const LinArgs &a, double x, double y, double z,
+__device__ __forceinline__ void acc_ndt(double *acc, const PoseK &a, double x, double y, double z,
                                         const double *__restrict__ c6, double d0, double d1, double d2) {
     // J = [I, -R skew(p)] (ndt.py:40); C symmetric inverse covariance
     const double C[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
@@ -142,22 +175,23 @@ __device__ __forceinline__ void acc_ndt(double *acc, const LinArgs &a, double x,
 
 // gather the matched record at cell-sorted index j and accumulate
 template <int KIND>
-__device__ __forceinline__ void accumulate(double *acc, const LinArgs &a, uint32_t j,
+__device__ __forceinline__ void accumulate(double *acc, const LinArgs &a, const PoseK &P, uint32_t j,
                                            float x, float y, float z, float tx, float ty, float tz) {
     if (KIND == PCR_ICP) {
         const PtF q = a.pts[j];
-        acc_icp(acc, a, x, y, z, (double)(tx - q.x), (double)(ty - q.y), (double)(tz - q.z));   // icp.py:39
+        acc_icp(acc, P, a.flags, x, y, z, (double)(tx - q.x), (double)(ty - q.y), (double)(tz - q.z));   // icp.py:39
     } else if (KIND == PCR_PLANE) {
-        const PtF q = a.pts[j];
-        const float4 nn = a.normals[j];
-        acc_plane(acc, a, x, y, z, nn.x, nn.y, nn.z, (double)(tx - q.x), (double)(ty - q.y), (double)(tz - q.z));
+        // point and normal from ONE 32-byte record (two 16-byte loads of the same sector)
+        const float4 *rec = reinterpret_cast<const float4 *>(a.pn + j);
+        const float4 q = rec[0], nn = rec[1];
+        acc_plane(acc, P, x, y, z, nn.x, nn.y, nn.z, (double)(tx - q.x), (double)(ty - q.y), (double)(tz - q.z));
     } else if (KIND == PCR_VPLANE) {
         const PtD q = a.means[j];
         const double *nn = a.vnorm + 3 * (size_t)j;
-        acc_plane(acc, a, x, y, z, nn[0], nn[1], nn[2], (double)tx - q.x, (double)ty - q.y, (double)tz - q.z);
+        acc_plane(acc, P, x, y, z, nn[0], nn[1], nn[2], (double)tx - q.x, (double)ty - q.y, (double)tz - q.z);
     } else {
         const PtD q = a.means[j];
-        acc_ndt(acc, a, x, y, z, a.vicov + 6 * (size_t)j, (double)tx - q.x, (double)ty - q.y, (double)tz - q.z);
+        acc_ndt(acc, P, x, y, z, a.vicov + 6 * (size_t)j, (double)tx - q.x, (double)ty - q.y, (double)tz - q.z);
     }
 }
 
@@ -230,6 +264,8 @@ struct TileIter {
 // ---- variant 0: everything in one kernel ----------------------------------------------------
 template <int KIND>
 __global__ void __launch_bounds__(256) k_linearize(const LinArgs a) {
+    PoseK P;
+    if (!load_pose<true>(a, P)) return;
     double acc[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = 0.0;
@@ -237,7 +273,7 @@ __global__ void __launch_bounds__(256) k_linearize(const LinArgs a) {
     for (int64_t i = it.base; i < it.end; i += it.stride) {
         const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
         float tx, ty, tz;
-        xform(a, x, y, z, tx, ty, tz);
+        xform(P, x, y, z, tx, ty, tz);
         uint32_t bj, bo;
         bool ok;
         if (KIND == PCR_ICP || KIND == PCR_PLANE) {
@@ -249,7 +285,7 @@ __global__ void __launch_bounds__(256) k_linearize(const LinArgs a) {
             nn_search<double, PtD>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz, a.bound2_d, best, bj, bo);
             ok = bj != PCR_NONE && __builtin_sqrt(best) < a.md_d;                 // voxelized_plane_icp.py:38
         }
-        if (ok) accumulate<KIND>(acc, a, bj, x, y, z, tx, ty, tz);
+        if (ok) accumulate<KIND>(acc, a, P, bj, x, y, z, tx, ty, tz);
     }
     block_store_partials(acc, a.partials);
 }
@@ -257,9 +293,14 @@ __global__ void __launch_bounds__(256) k_linearize(const LinArgs a) {
 // ---- variant 1: NN kernel (few registers, high occupancy) + streaming reduce kernel ---------
 // The cost of a query varies by more than 10x with its distance to the surface, so waves pull
 // 64-point tiles from a per-XCD counter instead of owning a fixed share: every wave stays busy
-// until its XCD's span of the scan is exhausted (k_finalize re-zeroes the counters).
-template <int VOXEL>
+// until its XCD's span of the scan is exhausted (the finalize step re-zeroes the counters).
+// SEED: the match of the PREVIOUS pass over this scan against this target (still in nn_j) starts
+// the search: any real target point is an exact upper bound, so only cells inside that radius are
+// looked at (the result is the same exact nearest neighbour).
+template <int VOXEL, int SEED>
 __global__ void __launch_bounds__(256) k_nn_scan(const LinArgs a) {
+    PoseK P;
+    if (!load_pose<false>(a, P)) return;
     const int xcd = (int)(blockIdx.x & 7);
     const int64_t span = (((a.n + 7) >> 3) + 63) & ~(int64_t)63;
     const int64_t lo = span * xcd;
@@ -273,17 +314,21 @@ __global__ void __launch_bounds__(256) k_nn_scan(const LinArgs a) {
         if (lo + (int64_t)t * 64 >= end) break;
         if (i >= end) continue;
         const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
+        uint32_t pj = PCR_NONE;
+        if (SEED) pj = a.nn_j[i];
         float tx, ty, tz;
-        xform(a, x, y, z, tx, ty, tz);
-        uint32_t bj, bo;
+        xform(P, x, y, z, tx, ty, tz);
+        uint32_t bj = PCR_NONE, bo = PCR_NONE;
         bool ok;
         if (!VOXEL) {
-            float best;
-            nn_search<float, PtF>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
+            float best = a.bound2_f;
+            if (SEED && pj != PCR_NONE) nn_test<float, PtF>(a.pts[pj], pj, tx, ty, tz, best, bj, bo);
+            nn_search<float, PtF, false, true>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
             ok = bj != PCR_NONE && __builtin_sqrtf(best) < a.md_f;
         } else {
-            double best;
-            nn_search<double, PtD>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz, a.bound2_d, best, bj, bo);
+            double best = a.bound2_d;
+            if (SEED && pj != PCR_NONE) nn_test<double, PtD>(a.means[pj], pj, (double)tx, (double)ty, (double)tz, best, bj, bo);
+            nn_search<double, PtD, false, true>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz, a.bound2_d, best, bj, bo);
             ok = bj != PCR_NONE && __builtin_sqrt(best) < a.md_d;
         }
         a.nn_j[i] = ok ? bj : PCR_NONE;
@@ -305,7 +350,7 @@ __global__ void __launch_bounds__(256) k_nn_counters(const LinArgs a, unsigned l
         const bool live = i < it.end;
         if (live) {
             const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
-            xform(a, x, y, z, tx, ty, tz);
+            xform(a.hp, x, y, z, tx, ty, tz);
         }
         uint32_t bj = PCR_NONE, bo = PCR_NONE; float best = a.bound2_f;
         NNCell<float> c = nn_cell<float>(a.gf, tx, ty, tz, a.bound2_f);
@@ -338,11 +383,19 @@ struct FinArgs {
     uint32_t *tile_ctr;        // 64 B apart: [0..7] tile counters, [8..15] group tickets, [16] leader tickets
     int nblocks;
     int kind;
-    double R[9];
+    double R[9];               // rotation of the pose when it came by value (pose == NULL)
     double *out;               // 32 doubles in HBM
     double *host_out;          // optional: the same 29 values straight into pinned host memory ...
     volatile uint32_t *host_flag;   // ... followed by this sequence number (host spins on it)
     uint32_t seq;
+    // device-resident Gauss-Newton loop (pcr_align; registration.py:89-111 behind the boundary)
+    PoseDev *pose;             // NULL: plain pass
+    int gn_inline;             // 1: solve + boxplus right after the fold; 0: k_gn_update does it after the all-reduce
+    int max_iter;
+    double tol;
+    double *trace;             // [max_iter][45]: pose before the step (16) + the 29 sums
+    double *host_T;            // pinned: the pose after the step ...
+    volatile unsigned long long *host_state;   // ... then (done << 32 | passes completed), one 8-byte store
 };
 
 // tot[0..31] (shared memory, complete before the call) -> the 29-vector in HBM and, optionally, in
@@ -355,6 +408,7 @@ __device__ __forceinline__ void finalize_emit(const FinArgs &f, const double *to
         } else {
             // H_ll = M I (icp.py:43); H_lr = -R skew(sum p) (icp.py:44); H_rr from the second
             // moments (math_tools.py:44-58)
+            const double *R = f.pose ? f.pose->R : f.R;
             const double cnt = tot[0], sx = tot[1], sy = tot[2], sz = tot[3];
             const double S[9] = {0, -sz, sy, sz, 0, -sx, -sy, sx, 0};
             double H[6][6];
@@ -363,7 +417,7 @@ __device__ __forceinline__ void finalize_emit(const FinArgs &f, const double *to
             for (int i = 0; i < 3; ++i)
                 for (int j = 0; j < 3; ++j) {
                     double v = 0.0;
-                    for (int k = 0; k < 3; ++k) v += f.R[3 * i + k] * S[3 * k + j];
+                    for (int k = 0; k < 3; ++k) v += R[3 * i + k] * S[3 * k + j];
                     H[i][3 + j] = -v;
                 }
             const double xx = tot[4], xy = tot[5], xz = tot[6], yy = tot[7], yz = tot[8], zz = tot[9];
@@ -381,6 +435,58 @@ __device__ __forceinline__ void finalize_emit(const FinArgs &f, const double *to
             *f.host_flag = f.seq;
         }
     }
+}
+
+// The O(1) tail of an iteration on the device (ONE thread): record the trace row, dx = -solve(H, g),
+// |dx| < tol test, T <- plus(T, dx), derived float32 / rotation copies for the next pass, progress
+// words for the host.  out29 is complete and visible to this thread.
+__device__ __forceinline__ void gn_update(const FinArgs &f, double (*A)[7]) {
+    PoseDev *p = f.pose;
+    const int it = p->iter;
+    double T[16];
+    for (int i = 0; i < 16; ++i) T[i] = p->T[i];
+    if (f.trace) {
+        double *row = f.trace + (size_t)it * 45;
+        for (int i = 0; i < 16; ++i) row[i] = T[i];
+        for (int i = 0; i < 29; ++i) row[16 + i] = f.out[i];
+    }
+    const int r = gn_step(A, f.out, f.tol, T);
+    int done = r == 2 ? PCR_LOOP_SINGULAR : (r == 1 ? PCR_LOOP_CONVERGED : PCR_LOOP_RUNNING);
+    if (r == 0) {
+        for (int i = 0; i < 16; ++i) p->T[i] = T[i];
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) { p->R[3 * i + j] = T[4 * i + j]; p->r32[3 * i + j] = (float)T[4 * i + j]; }
+            p->t32[i] = (float)T[4 * i + 3];
+        }
+    }
+    const int it1 = it + 1;
+    if (done == PCR_LOOP_RUNNING && it1 >= f.max_iter) done = PCR_LOOP_MAXITER;
+    p->iter = it1;
+    p->done = done;
+    if (f.host_T) {
+        for (int i = 0; i < 16; ++i) f.host_T[i] = T[i];
+        __threadfence_system();
+        *f.host_state = ((unsigned long long)(unsigned)done << 32) | (unsigned)it1;
+    }
+}
+
+// multi-GPU loop: the step after the all-reduce of the 29 sums (every rank computes the same update)
+__global__ void __launch_bounds__(64) k_gn_update(const FinArgs f) {
+    __shared__ double A[6][7];
+    if (threadIdx.x == 0 && f.pose->done == PCR_LOOP_RUNNING) gn_update(f, A);
+}
+
+// start of pcr_align: the initial pose into HBM (kernel arguments: no host-to-device copy)
+struct PoseInit { double T[16]; };
+__global__ void __launch_bounds__(64) k_pose_init(PoseDev *p, const PoseInit init, int max_iter) {
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < 16; ++i) p->T[i] = init.T[i];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) { p->R[3 * i + j] = init.T[4 * i + j]; p->r32[3 * i + j] = (float)init.T[4 * i + j]; }
+        p->t32[i] = (float)init.T[4 * i + 3];
+    }
+    p->iter = 0;
+    p->done = max_iter > 0 ? PCR_LOOP_RUNNING : PCR_LOOP_MAXITER;
 }
 
 // Stand-alone fold (variant 0, and PCR_FUSE_FINALIZE=0): ONE block of NT threads.
@@ -422,12 +528,18 @@ __device__ __forceinline__ void finalize_body(const FinArgs &f) {
     }
     __syncthreads();
     finalize_emit(f, tot);
+    if (f.pose && f.gn_inline && threadIdx.x == 0) gn_update(f, reinterpret_cast<double (*)[7]>(&part[0][0]));
 }
 
-__global__ void __launch_bounds__(1024) k_finalize(const FinArgs f) { finalize_body<1024>(f); }
+__global__ void __launch_bounds__(1024) k_finalize(const FinArgs f) {
+    if (f.pose && f.pose->done != PCR_LOOP_RUNNING) return;
+    finalize_body<1024>(f);
+}
 
 template <int KIND>
 __global__ void __launch_bounds__(256) k_reduce(const LinArgs a) {
+    PoseK P;
+    if (!load_pose<true>(a, P)) return;
     double acc[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = 0.0;
@@ -437,8 +549,8 @@ __global__ void __launch_bounds__(256) k_reduce(const LinArgs a) {
         if (j == PCR_NONE) continue;
         const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
         float tx, ty, tz;
-        xform(a, x, y, z, tx, ty, tz);
-        accumulate<KIND>(acc, a, j, x, y, z, tx, ty, tz);
+        xform(P, x, y, z, tx, ty, tz);
+        accumulate<KIND>(acc, a, P, j, x, y, z, tx, ty, tz);
     }
     block_store_partials(acc, a.partials);
 }
@@ -452,6 +564,8 @@ __global__ void __launch_bounds__(256) k_reduce(const LinArgs a) {
 // atomics instead of nblocks, and no separate k_finalize launch.
 template <int KIND>
 __global__ void __launch_bounds__(256) k_reduce_finalize(const LinArgs a, const FinArgs f) {
+    PoseK P;
+    if (!load_pose<true>(a, P)) return;
     double acc[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = 0.0;
@@ -461,8 +575,8 @@ __global__ void __launch_bounds__(256) k_reduce_finalize(const LinArgs a, const 
         if (j == PCR_NONE) continue;
         const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
         float tx, ty, tz;
-        xform(a, x, y, z, tx, ty, tz);
-        accumulate<KIND>(acc, a, j, x, y, z, tx, ty, tz);
+        xform(P, x, y, z, tx, ty, tz);
+        accumulate<KIND>(acc, a, P, j, x, y, z, tx, ty, tz);
     }
     block_store_partials<true>(acc, a.partials);
 
@@ -472,9 +586,14 @@ __global__ void __launch_bounds__(256) k_reduce_finalize(const LinArgs a, const 
     const int g = (int)(blockIdx.x & 7), per = f.nblocks >> 3;
     uint32_t *ctr1 = &f.tile_ctr[(8 + g) * 16], *ctr2 = &f.tile_ctr[16 * 16];
     double *rows = const_cast<double *>(f.partials);
+    // Hand-off protocol (MI355X guide, "sc1 payload -> drained vmcnt -> sc1 flag"): the 32 partial sums
+    // were stored write-through at agent scope by lanes 0..31 of THIS wave; the explicit s_waitcnt below
+    // (inline asm: the compiler cannot drop or move it) makes the wave wait until those stores have
+    // been acknowledged by memory before the ticket atomic is issued, so a block on another XCD that
+    // observes the ticket also observes the rows.  The folding block reads the rows with agent-scope
+    // (sc1, L1-bypassing) loads issued after its own ticket returned.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (threadIdx.x == 0) {
-        // the 32 partial stores were issued by this wave: wait for their completion, then take a ticket
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         const uint32_t t = __hip_atomic_fetch_add(ctr1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         role = t == (uint32_t)(per - 1);
     }
@@ -503,9 +622,9 @@ __global__ void __launch_bounds__(256) k_reduce_finalize(const LinArgs a, const 
         const double t = ((part[0][k] + part[1][k]) + (part[2][k] + part[3][k])) + ((part[4][k] + part[5][k]) + (part[6][k] + part[7][k]));
         __hip_atomic_store(&rows[(size_t)(f.nblocks + g) * 32 + k], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // group row stored (lanes 0..31 of wave 0)
     if (threadIdx.x == 0) {
         __hip_atomic_store(ctr1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // re-armed for the next pass
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         const uint32_t t2 = __hip_atomic_fetch_add(ctr2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         role = t2 == 7u;
     }
@@ -523,6 +642,8 @@ __global__ void __launch_bounds__(256) k_reduce_finalize(const LinArgs a, const 
     }
     __syncthreads();
     finalize_emit(f, tot);
+    // every other block has stored its partials, i.e. has long read the pose: safe to rewrite it
+    if (f.pose && f.gn_inline && threadIdx.x == 0) gn_update(f, reinterpret_cast<double (*)[7]>(&part[0][0]));
 }
 
 // after the RCCL all-reduce: hand the 29 doubles to the host the same zero-copy way k_finalize does
@@ -553,45 +674,55 @@ __global__ void __launch_bounds__(256) k_nn_query(Geom<Real> g, const PT *pts, c
 // host side
 // =============================================================================================
 pcr_status pcr_ensure_scratch(pcr_context *ctx, int64_t n_points) {
+    (void)n_points;
     if (!ctx->d_partials) {
-        ctx->max_blocks = ctx->num_cu * 16;
-        HIP_TRY(hipMalloc(&ctx->d_partials, sizeof(double) * 32 * (size_t)ctx->max_blocks));
+        ctx->max_blocks = (ctx->num_cu * 16 + 7) & ~7;
+        // + 8 rows: the group sums of k_reduce_finalize live behind the per-block rows
+        HIP_TRY(hipMalloc(&ctx->d_partials, sizeof(double) * 32 * (size_t)(ctx->max_blocks + 8)));
         HIP_TRY(hipMalloc(&ctx->d_out, sizeof(double) * 32));
-        HIP_TRY(hipHostMalloc(&ctx->h_out, sizeof(double) * 40, hipHostMallocMapped | hipHostMallocCoherent));
-        memset(ctx->h_out, 0, sizeof(double) * 40);
+        HIP_TRY(hipMalloc(&ctx->d_pose, sizeof(PoseDev)));
+        // pinned + mapped: [0..28] sums, [32] sequence number (pcr_linearize); [40..55] pose, [56] loop state (pcr_align)
+        HIP_TRY(hipHostMalloc(&ctx->h_out, sizeof(double) * 64, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(ctx->h_out, 0, sizeof(double) * 64);
         HIP_TRY(hipHostGetDevicePointer((void **)&ctx->h_out_dev, ctx->h_out, 0));
         HIP_TRY(hipMalloc(&ctx->d_tile_ctr, sizeof(uint32_t) * 17 * 16));      // 8 tile counters + 8 + 1 tickets
         HIP_TRY(hipMemsetAsync(ctx->d_tile_ctr, 0, sizeof(uint32_t) * 17 * 16, ctx->stream));
         for (int v = 0; v < 2; ++v) {
             int nb = 0;
-            hipError_t e = v == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<0>, 256, 0)
-                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<1>, 256, 0);
+            hipError_t e = v == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<0, 0>, 256, 0)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<1, 0>, 256, 0);
             ctx->nn_blocks_per_cu[v] = (e == hipSuccess && nb > 0) ? nb : 4;
         }
-    }
-    if (ctx->variant == 1 && ctx->nn_cap < n_points) {
-        if (ctx->d_nn_j) HIP_TRY(hipFree(ctx->d_nn_j));
-        ctx->d_nn_j = nullptr;
-        HIP_TRY(hipMalloc(&ctx->d_nn_j, sizeof(uint32_t) * (size_t)n_points));
-        ctx->nn_cap = n_points;
     }
     return PCR_OK;
 }
 
 static int choose_blocks(const pcr_context *ctx, int64_t n) {
     // enough 256-thread blocks to fill every CU several times over, never more than the work,
-    // always a multiple of 8 (one contiguous span of the scan per XCD)
+    // always a multiple of 8 (one contiguous span of the scan per XCD; odd CU counts round down)
     int64_t want = (n + 255) / 256;
     int64_t cap = (int64_t)ctx->num_cu * 8;
     int64_t nb = want < cap ? want : cap;
     nb = (nb + 7) & ~(int64_t)7;
-    if (nb < 8) nb = 8;
     if (nb > ctx->max_blocks) nb = ctx->max_blocks;
+    nb &= ~(int64_t)7;
+    if (nb < 8) nb = 8;
     return (int)nb;
 }
 
-pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double T[16], double max_dist,
-                             unsigned flags, double out[29]) {
+// ---- one pass = NN kernel + reduce kernel (variant 1) or the fused kernel (variant 0) ------------
+struct Pass {
+    pcr_context *ctx;
+    pcr_target *t;
+    pcr_scan *s;
+    int kind;
+    LinArgs a;
+    FinArgs f;
+    bool fused_fin;      // k_reduce_finalize instead of k_reduce + k_finalize
+    bool seed;           // the scan holds matches against this very target: seed the search with them
+};
+
+static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, double max_dist, unsigned flags) {
     pcr_context *ctx = t->ctx;
     PCR_REQUIRE(s->ctx == ctx, "scan and target belong to different contexts");
     PCR_REQUIRE(kind >= PCR_ICP && kind <= PCR_NDT, "unknown kind");
@@ -604,47 +735,67 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
         pcr_set_error("kind %d needs a voxel target", kind);
         return PCR_ERR_NO_TARGET;
     }
-    if (kind == PCR_PLANE && !t->normals) { pcr_set_error("PlaneICP target has no normals"); return PCR_ERR_NO_TARGET; }
+    if (kind == PCR_PLANE && !t->pn) { pcr_set_error("PlaneICP target has no normals"); return PCR_ERR_NO_TARGET; }
     if (kind == PCR_VPLANE && !t->vnorm) { pcr_set_error("VPlaneICP target has no voxel normals"); return PCR_ERR_NO_TARGET; }
     if (kind == PCR_NDT && !t->vicov) { pcr_set_error("NDT target has no inverse covariances"); return PCR_ERR_NO_TARGET; }
     HIP_TRY(hipSetDevice(ctx->device));
     PCR_TRY(pcr_ensure_scratch(ctx, s->n));
-
-    LinArgs a;
+    if (ctx->variant == 1 && !s->nn_j) {
+        HIP_TRY(hipMalloc(&s->nn_j, sizeof(uint32_t) * (size_t)(s->n > 0 ? s->n : 1)));
+        s->nn_serial = 0;
+    }
+    ps->ctx = ctx; ps->t = t; ps->s = s; ps->kind = kind;
+    LinArgs &a = ps->a;
+    memset(&a, 0, sizeof a);
     a.sx = s->x; a.sy = s->y; a.sz = s->z; a.n = s->n;
-    a.gf = t->gf; a.pts = t->pts; a.normals = t->normals;
+    a.gf = t->gf; a.pts = t->pts; a.pn = t->pn;
     a.gd = t->gd; a.means = t->means; a.vnorm = t->vnorm; a.vicov = t->vicov;
     a.cell_start = t->cell_start;
-    for (int i = 0; i < 3; ++i) {
-        for (int j = 0; j < 3; ++j) { a.R[3 * i + j] = T[4 * i + j]; a.r32[3 * i + j] = (float)T[4 * i + j]; }
-        a.t32[i] = (float)T[4 * i + 3];
-    }
     a.md_f = (float)max_dist; a.md_d = max_dist;
     const double bound = max_dist * (1.0 + 1e-6);
     a.bound2_f = (float)(bound * bound); a.bound2_d = bound * bound;
     a.flags = flags;
     a.nblocks = choose_blocks(ctx, s->n);
     a.partials = ctx->d_partials;
-    a.nn_j = ctx->d_nn_j; a.tile_ctr = ctx->d_tile_ctr;
-
+    a.nn_j = s->nn_j; a.tile_ctr = ctx->d_tile_ctr;
     if (ctx->variant == 1 && a.nblocks > ctx->num_cu * 4) a.nblocks = ctx->num_cu * 4;   // k_reduce streams: 4 blocks/CU
-    const bool fused_fin = ctx->variant == 1 && ctx->fuse_finalize;       // k_reduce_finalize instead of k_reduce + k_finalize
-    ProfEvent ev;
-    const dim3 grid(a.nblocks), block(256);
-
-    FinArgs f;
+    // TileIter and the ticket counts of k_reduce_finalize need a multiple of 8 blocks
+    a.nblocks &= ~7;
+    if (a.nblocks < 8) a.nblocks = 8;
+    ps->fused_fin = ctx->variant == 1 && ctx->fuse_finalize;
+    ps->seed = ctx->variant == 1 && ctx->nn_mode == 1 && s->nn_serial == t->serial && s->nn_serial != 0;
+    FinArgs &f = ps->f;
+    memset(&f, 0, sizeof f);
     f.partials = ctx->d_partials; f.tile_ctr = ctx->d_tile_ctr; f.nblocks = a.nblocks; f.kind = kind; f.out = ctx->d_out;
-    for (int i = 0; i < 9; ++i) f.R[i] = a.R[i];
-    // single GPU: the finalize step writes the result and a sequence number straight into pinned host
-    // memory (no copy command, no stream query); with a communicator the all-reduce sits in between
-    const bool direct = ctx->comm == nullptr && ctx->h_out_dev != nullptr;
-    volatile uint32_t *flag = (volatile uint32_t *)(ctx->h_out + 32);
-    f.host_out = direct ? ctx->h_out_dev : nullptr;
-    f.host_flag = direct ? (volatile uint32_t *)(ctx->h_out_dev + 32) : nullptr;
-    f.seq = ++ctx->seq;
+    return PCR_OK;
+}
+
+static void pass_set_host_pose(Pass *ps, const double T[16]) {
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) {
+            ps->a.hp.R[3 * i + j] = T[4 * i + j]; ps->a.hp.r32[3 * i + j] = (float)T[4 * i + j];
+            ps->f.R[3 * i + j] = T[4 * i + j];
+        }
+        ps->a.hp.t32[i] = (float)T[4 * i + 3];
+    }
+    ps->a.pose = nullptr; ps->f.pose = nullptr;
+}
+
+template <int KIND>
+static void launch_reduce_kind(const Pass *ps, bool fused, dim3 grid) {
+    if (fused) hipLaunchKernelGGL(k_reduce_finalize<KIND>, grid, dim3(256), 0, ps->ctx->stream, ps->a, ps->f);
+    else hipLaunchKernelGGL(k_reduce<KIND>, grid, dim3(256), 0, ps->ctx->stream, ps->a);
+}
+
+// enqueue the kernels of one pass on the context's stream (no waiting)
+static pcr_status pass_enqueue(Pass *ps) {
+    pcr_context *ctx = ps->ctx;
+    const LinArgs &a = ps->a;
+    const dim3 grid(a.nblocks), block(256);
+    ProfEvent ev;
     if (ctx->variant == 0) {
         pcr_prof_begin(ctx, PCR_K_LINEARIZE, &ev);
-        switch (kind) {
+        switch (ps->kind) {
         case PCR_ICP: hipLaunchKernelGGL(k_linearize<PCR_ICP>, grid, block, 0, ctx->stream, a); break;
         case PCR_PLANE: hipLaunchKernelGGL(k_linearize<PCR_PLANE>, grid, block, 0, ctx->stream, a); break;
         case PCR_VPLANE: hipLaunchKernelGGL(k_linearize<PCR_VPLANE>, grid, block, 0, ctx->stream, a); break;
@@ -654,50 +805,81 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
     } else {
         pcr_prof_begin(ctx, PCR_K_NN, &ev);
         {   // exactly one resident generation of waves; they share the tiles dynamically
-            int64_t nb = (int64_t)ctx->num_cu * ctx->nn_blocks_per_cu[t->is_voxel ? 1 : 0];
-            const int64_t need = ((s->n + 63) / 64 + 3) / 4;
+            const bool vox = ps->t->is_voxel != 0;
+            int64_t nb = (int64_t)ctx->num_cu * ctx->nn_blocks_per_cu[vox ? 1 : 0];
+            const int64_t need = ((a.n + 63) / 64 + 3) / 4;
             if (nb > need) nb = need;
             nb = (nb + 7) & ~(int64_t)7;
             if (nb < 8) nb = 8;
             const dim3 nn_grid((unsigned)nb);
-            if (!t->is_voxel) hipLaunchKernelGGL(k_nn_scan<0>, nn_grid, block, 0, ctx->stream, a);
-            else hipLaunchKernelGGL(k_nn_scan<1>, nn_grid, block, 0, ctx->stream, a);
+            if (!vox) {
+                if (ps->seed) hipLaunchKernelGGL((k_nn_scan<0, 1>), nn_grid, block, 0, ctx->stream, a);
+                else hipLaunchKernelGGL((k_nn_scan<0, 0>), nn_grid, block, 0, ctx->stream, a);
+            } else {
+                if (ps->seed) hipLaunchKernelGGL((k_nn_scan<1, 1>), nn_grid, block, 0, ctx->stream, a);
+                else hipLaunchKernelGGL((k_nn_scan<1, 0>), nn_grid, block, 0, ctx->stream, a);
+            }
+            ps->s->nn_serial = ps->t->serial;      // nn_j now holds matches against this target
+            ps->seed = ctx->nn_mode == 1;          // ... which the next pass of a loop may start from
         }
         pcr_prof_end(ctx, &ev);
         pcr_prof_begin(ctx, PCR_K_REDUCE, &ev);
-        if (fused_fin) {
-            switch (kind) {
-            case PCR_ICP: hipLaunchKernelGGL(k_reduce_finalize<PCR_ICP>, grid, block, 0, ctx->stream, a, f); break;
-            case PCR_PLANE: hipLaunchKernelGGL(k_reduce_finalize<PCR_PLANE>, grid, block, 0, ctx->stream, a, f); break;
-            case PCR_VPLANE: hipLaunchKernelGGL(k_reduce_finalize<PCR_VPLANE>, grid, block, 0, ctx->stream, a, f); break;
-            default: hipLaunchKernelGGL(k_reduce_finalize<PCR_NDT>, grid, block, 0, ctx->stream, a, f); break;
-            }
-        } else {
-            switch (kind) {
-            case PCR_ICP: hipLaunchKernelGGL(k_reduce<PCR_ICP>, grid, block, 0, ctx->stream, a); break;
-            case PCR_PLANE: hipLaunchKernelGGL(k_reduce<PCR_PLANE>, grid, block, 0, ctx->stream, a); break;
-            case PCR_VPLANE: hipLaunchKernelGGL(k_reduce<PCR_VPLANE>, grid, block, 0, ctx->stream, a); break;
-            default: hipLaunchKernelGGL(k_reduce<PCR_NDT>, grid, block, 0, ctx->stream, a); break;
-            }
+        switch (ps->kind) {
+        case PCR_ICP: launch_reduce_kind<PCR_ICP>(ps, ps->fused_fin, grid); break;
+        case PCR_PLANE: launch_reduce_kind<PCR_PLANE>(ps, ps->fused_fin, grid); break;
+        case PCR_VPLANE: launch_reduce_kind<PCR_VPLANE>(ps, ps->fused_fin, grid); break;
+        default: launch_reduce_kind<PCR_NDT>(ps, ps->fused_fin, grid); break;
         }
         pcr_prof_end(ctx, &ev);
     }
     HIP_TRY(hipGetLastError());
-
-    if (!fused_fin) {
+    if (!ps->fused_fin) {
         pcr_prof_begin(ctx, PCR_K_FINALIZE, &ev);
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, ctx->stream, f);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, ctx->stream, ps->f);
         pcr_prof_end(ctx, &ev);
         HIP_TRY(hipGetLastError());
     }
+    return PCR_OK;
+}
+
+// spin on a word in pinned host memory that a kernel writes, then fall back to a blocking wait
+template <typename Pred>
+static pcr_status wait_host_word(pcr_context *ctx, Pred ready, const char *what) {
+    for (long spin = 0; spin < 4000000L; ++spin) {
+        if (ready()) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return PCR_OK; }
+        __builtin_ia32_pause();
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));     // very long pass (or a fault): block, then re-check
+    if (!ready()) { pcr_set_error("%s did not report completion", what); return PCR_ERR_HIP; }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return PCR_OK;
+}
+
+pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double T[16], double max_dist,
+                             unsigned flags, double out[29]) {
+    Pass ps;
+    PCR_TRY(pass_setup(&ps, t, s, kind, max_dist, flags));
+    pcr_context *ctx = ps.ctx;
+    pass_set_host_pose(&ps, T);
+    const bool use_comm = ctx->comm != nullptr && !(flags & PCR_FLAG_LOCAL_ONLY);
+    // single GPU: the finalize step writes the result and a sequence number straight into pinned host
+    // memory (no copy command, no stream query); with a communicator the all-reduce sits in between
+    const bool direct = !use_comm && ctx->h_out_dev != nullptr;
+    volatile uint32_t *flag = (volatile uint32_t *)(ctx->h_out + 32);
+    ps.f.host_out = direct ? ctx->h_out_dev : nullptr;
+    ps.f.host_flag = direct ? (volatile uint32_t *)(ctx->h_out_dev + 32) : nullptr;
+    const uint32_t seq = ++ctx->seq;
+    ps.f.seq = seq;
+    PCR_TRY(pass_enqueue(&ps));
 
     bool flagged = direct;
-    if (ctx->comm) {
+    if (use_comm) {
+        ProfEvent ev;
         pcr_prof_begin(ctx, PCR_K_ALLREDUCE, &ev);
         pcr_status cs = pcr_comm_allreduce29(ctx, ctx->d_out);
         if (cs == PCR_OK && ctx->h_out_dev) {
             hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, ctx->d_out, ctx->h_out_dev,
-                               (volatile uint32_t *)(ctx->h_out_dev + 32), f.seq);
+                               (volatile uint32_t *)(ctx->h_out_dev + 32), seq);
             flagged = true;
         }
         pcr_prof_end(ctx, &ev);
@@ -705,34 +887,103 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
         HIP_TRY(hipGetLastError());
     }
     if (flagged) {
-        bool seen = false;
-        for (long spin = 0; spin < 4000000L; ++spin) {
-            if (*flag == f.seq) { seen = true; break; }
-            __builtin_ia32_pause();
-        }
-        if (!seen) {                                   // very long pass (or a fault): block, then re-check
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-            if (*flag != f.seq) { pcr_set_error("finalize kernel did not report completion"); return PCR_ERR_HIP; }
-        }
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        PCR_TRY(wait_host_word(ctx, [&] { return *flag == seq; }, "finalize kernel"));
         for (int i = 0; i < 29; ++i) out[i] = ctx->h_out[i];
         return PCR_OK;
     }
     HIP_TRY(hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(double) * 29, hipMemcpyDeviceToHost, ctx->stream));
-    // The pass takes a fraction of a millisecond: poll the stream instead of sleeping in
-    // hipStreamSynchronize (whose wake-up latency can exceed the whole pass), then fall back.
-    {
-        hipError_t q = hipErrorNotReady;
-        for (int spin = 0; spin < 200000 && (q = hipStreamQuery(ctx->stream)) == hipErrorNotReady; ++spin) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 29; ++i) out[i] = ctx->h_out[i];
+    return PCR_OK;
+}
+
+// ---- Registration.align behind the boundary, device-resident (registration.py:71-113) -------------
+// The pose lives in HBM; every iteration is k_nn_scan + k_reduce_finalize whose last block also does
+// dx = -solve(H, g), the |dx| < tol test and T <- plus(T, dx) (gn_update).  The host only keeps the
+// queue a couple of iterations ahead of the GPU and watches two words in pinned memory: no host round
+// trip, no device-to-host copy and no host solve between iterations.  Launches that arrive after
+// convergence see pose->done and return at once.  With a communicator the 29 sums are all-reduced
+// between the fold and the step (k_gn_update); iterations are then enqueued in fixed batches so that
+// every rank issues the same sequence of collectives.
+pcr_status pcr_run_align(pcr_target *t, pcr_scan *s, int kind, const double T_init[16], int max_iter, double tol,
+                         double max_dist, unsigned flags, double T_out[16], int *iterations, double *trace_or_null) {
+    Pass ps;
+    PCR_TRY(pass_setup(&ps, t, s, kind, max_dist, flags));
+    pcr_context *ctx = ps.ctx;
+    if (max_iter <= 0) {
+        memcpy(T_out, T_init, 16 * sizeof(double));
+        if (iterations) *iterations = 0;
+        return PCR_OK;
+    }
+    if (ctx->trace_cap < max_iter) {
+        if (ctx->d_trace) HIP_TRY(hipFree(ctx->d_trace));
+        ctx->d_trace = nullptr; ctx->trace_cap = 0;
+        HIP_TRY(hipMalloc(&ctx->d_trace, sizeof(double) * 45 * (size_t)max_iter));
+        ctx->trace_cap = max_iter;
+    }
+    const bool use_comm = ctx->comm != nullptr && !(flags & PCR_FLAG_LOCAL_ONLY);
+    volatile unsigned long long *state = (volatile unsigned long long *)(ctx->h_out + 56);
+    *state = 0;
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    ps.a.pose = ctx->d_pose;
+    FinArgs &f = ps.f;
+    f.pose = ctx->d_pose; f.gn_inline = use_comm ? 0 : 1; f.max_iter = max_iter; f.tol = tol;
+    f.trace = ctx->d_trace;
+    f.host_T = ctx->h_out_dev + 40;
+    f.host_state = (volatile unsigned long long *)(ctx->h_out_dev + 56);
+    PoseInit init;
+    memcpy(init.T, T_init, sizeof init.T);
+    hipLaunchKernelGGL(k_pose_init, dim3(1), dim3(64), 0, ctx->stream, ctx->d_pose, init, max_iter);
+    HIP_TRY(hipGetLastError());
+
+    auto passes_done = [&] { return (int)(unsigned)(*state & 0xffffffffull); };
+    auto loop_done = [&] { return (int)(unsigned)(*state >> 32); };
+    int enq = 0;
+    if (!use_comm) {
+        const int AHEAD = 2;            // iterations kept in the queue beyond the one the GPU reports
+        long spin = 0;
+        for (;;) {
+            if (loop_done() != PCR_LOOP_RUNNING) break;
+            const int fin = passes_done();
+            if (enq < max_iter && enq < fin + AHEAD) { PCR_TRY(pass_enqueue(&ps)); ++enq; spin = 0; continue; }
             __builtin_ia32_pause();
+            if (++spin > 4000000L) {    // a very long pass (or a fault): block, then look again
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+                if (loop_done() == PCR_LOOP_RUNNING && passes_done() == fin && !(enq < max_iter)) {
+                    pcr_set_error("device Gauss-Newton loop made no progress");
+                    return PCR_ERR_HIP;
+                }
+                spin = 0;
+            }
         }
-        if (q == hipErrorNotReady) q = hipStreamSynchronize(ctx->stream);
-        if (q != hipSuccess) {
-            pcr_set_error("stream wait failed: %s", hipGetErrorString(q));
-            return PCR_ERR_HIP;
+    } else {
+        const int BATCH = 4;
+        while (loop_done() == PCR_LOOP_RUNNING && enq < max_iter) {
+            for (int b = 0; b < BATCH && enq < max_iter; ++b, ++enq) {
+                PCR_TRY(pass_enqueue(&ps));
+                ProfEvent ev;
+                pcr_prof_begin(ctx, PCR_K_ALLREDUCE, &ev);
+                pcr_status cs = pcr_comm_allreduce29(ctx, ctx->d_out);
+                pcr_prof_end(ctx, &ev);
+                if (cs != PCR_OK) return cs;
+                hipLaunchKernelGGL(k_gn_update, dim3(1), dim3(64), 0, ctx->stream, f);
+                HIP_TRY(hipGetLastError());
+            }
+            HIP_TRY(hipStreamSynchronize(ctx->stream));    // every rank reads the same state here
         }
     }
-    for (int i = 0; i < 29; ++i) out[i] = ctx->h_out[i];
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    const int done = loop_done(), it = passes_done();
+    for (int i = 0; i < 16; ++i) T_out[i] = ctx->h_out[40 + i];
+    if (iterations) *iterations = it;
+    if (trace_or_null && it > 0) {
+        HIP_TRY(hipMemcpyAsync(trace_or_null, ctx->d_trace, sizeof(double) * 45 * (size_t)it, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    if (done == PCR_LOOP_SINGULAR) {
+        pcr_set_error("Singular matrix");
+        return PCR_ERR_SINGULAR;
+    }
     return PCR_OK;
 }
 
@@ -774,8 +1025,8 @@ extern "C" pcr_status pcr_nn_counters(pcr_target *t, pcr_scan *s, const double T
     a.sx = s->x; a.sy = s->y; a.sz = s->z; a.n = s->n;
     a.gf = t->gf; a.pts = t->pts; a.cell_start = t->cell_start;
     for (int i = 0; i < 3; ++i) {
-        for (int j = 0; j < 3; ++j) a.r32[3 * i + j] = (float)T[4 * i + j];
-        a.t32[i] = (float)T[4 * i + 3];
+        for (int j = 0; j < 3; ++j) a.hp.r32[3 * i + j] = (float)T[4 * i + j];
+        a.hp.t32[i] = (float)T[4 * i + 3];
     }
     const double bound = max_dist * (1.0 + 1e-6);
     a.bound2_f = (float)(bound * bound);

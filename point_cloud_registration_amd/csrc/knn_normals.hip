@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn_query(Geom<float> g, const Pt
 
 // normals of the target's own points, processed (and written) in cell-sorted order
 __global__ void __launch_bounds__(KNN_BLOCK) k_knn_normals(Geom<float> g, const PtF *pts, const uint32_t *cs, int64_t n,
-                                                           int k, int compat, float4 *normals) {
+                                                           int k, int compat, PtN *pn) {
     const int64_t i = (int64_t)blockIdx.x * KNN_BLOCK + threadIdx.x;
     if (i >= n) return;
     KnnList L = knn_list(k);
@@ -173,7 +173,10 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn_normals(Geom<float> g, const 
     }
     double nv[3];
     smallest_eigvec3(c, nv);
-    normals[i] = make_float4((float)nv[0], (float)nv[1], (float)nv[2], 0.f);
+    PtN r;                                      // the PlaneICP gather record: point + normal in 32 bytes
+    r.x = me.x; r.y = me.y; r.z = me.z; r.orig = pt_orig(me);
+    r.nx = (float)nv[0]; r.ny = (float)nv[1]; r.nz = (float)nv[2]; r.pad = 0;
+    pn[i] = r;
 }
 
 static pcr_status check_k(int k) {
@@ -210,11 +213,11 @@ extern "C" pcr_status pcr_target_estimate_normals(pcr_target *t, int k, int comp
     PCR_TRY(check_k(k));
     pcr_context *ctx = t->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
-    if (!t->normals) HIP_TRY(hipMalloc(&t->normals, sizeof(float4) * (size_t)(t->n ? t->n : 1)));
+    if (!t->pn) HIP_TRY(hipMalloc(&t->pn, sizeof(PtN) * (size_t)(t->n ? t->n : 1)));
     if (t->n > 0) {
         const size_t smem = 3 * sizeof(float) * (size_t)k * KNN_BLOCK;
         hipLaunchKernelGGL(k_knn_normals, dim3((unsigned)((t->n + KNN_BLOCK - 1) / KNN_BLOCK)), dim3(KNN_BLOCK), smem,
-                           ctx->stream, t->gf, t->pts, t->cell_start, t->n, k, compat, t->normals);
+                           ctx->stream, t->gf, t->pts, t->cell_start, t->n, k, compat, t->pn);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }

@@ -228,12 +228,14 @@ __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restri
 
 // On return: bj = cell-sorted index of the nearest point (PCR_NONE if nothing closer than
 // sqrt(bound2)), best = its squared distance, borig = its original index.
-template <typename Real, typename PT, bool STATS = false>
+// SEEDED: best / bj / borig come in holding a real target point (any point is an exact upper bound:
+// the search then only has to look inside that radius) or (bound2, PCR_NONE, PCR_NONE).
+template <typename Real, typename PT, bool STATS = false, bool SEEDED = false>
 __device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restrict__ pts,
                                           const uint32_t *__restrict__ cs,
                                           Real qx, Real qy, Real qz, Real bound2,
                                           Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr) {
-    best = bound2; bj = PCR_NONE; borig = PCR_NONE;
+    if (!SEEDED) { best = bound2; bj = PCR_NONE; borig = PCR_NONE; }
     const NNCell<Real> c = nn_cell<Real>(g, qx, qy, qz, bound2);
     const int kstart = nn_ring0<Real, PT, STATS>(g, pts, cs, c, qx, qy, qz, best, bj, borig, st);
     nn_rings<Real, PT, STATS>(g, pts, cs, c, kstart, qx, qy, qz, best, bj, borig, st);

@@ -54,6 +54,29 @@ struct Geom {
 // points of a grid, cell-sorted: xyz + original index bit-cast into w
 typedef float4 PtF;
 typedef double4 PtD;
+// PlaneICP gather record, cell-sorted, 32-byte aligned: the matched point AND its normal arrive in
+// ONE 32-byte sector (two separate float4 arrays cost two 64-byte lines per correspondence once the
+// target outgrows the caches: 94 vs 40 algorithmic bytes per query at 1e8 points)
+struct __attribute__((aligned(32))) PtN {
+    float x, y, z;
+    uint32_t orig;
+    float nx, ny, nz;
+    uint32_t pad;
+};
+
+// Device-resident state of the Gauss-Newton loop (pcr_align): the pose every kernel of an iteration
+// reads, rewritten by the last block of the reduce kernel (solve + boxplus on the device).
+struct PoseDev {
+    double T[16];          // current pose, row-major
+    double R[9];           // = T[:3,:3]
+    float r32[9], t32[3];  // float32 copy used to transform the scan (math_tools.py:111-113)
+    int iter;              // passes completed
+    int done;              // 0 running, 1 converged, 2 singular, 3 max_iter reached
+};
+#define PCR_LOOP_RUNNING 0
+#define PCR_LOOP_CONVERGED 1
+#define PCR_LOOP_SINGULAR 2
+#define PCR_LOOP_MAXITER 3
 
 // Device allocation released on scope exit unless handed over with release(): every early return
 // of the HIP_TRY / PCR_TRY macros leaves no temporaries behind.
@@ -100,10 +123,14 @@ struct pcr_context {
     double *h_out = nullptr;        // pinned + mapped: 32 doubles, then the completion sequence number
     double *h_out_dev = nullptr;    // device-side address of h_out
     uint32_t seq = 0;
-    // variant-1 scratch (NN results in HBM)
-    uint32_t *d_nn_j = nullptr;
-    int64_t nn_cap = 0;
+    // device-resident Gauss-Newton loop: pose in HBM, per-iteration trace rows (16 + 29 doubles),
+    // progress words in pinned host memory ([0] iter, [1] done, then 16 doubles of pose)
+    PoseDev *d_pose = nullptr;
+    double *d_trace = nullptr;
+    int trace_cap = 0;
     int variant = 0;
+    int nn_mode = 0;             // 0 per-lane gathers; 1 seed the bound with the previous match; 2 LDS-staged
+    uint64_t next_serial = 1;    // targets get unique serial numbers (validity of a scan's previous matches)
     bool fuse_finalize = true;   // k_reduce_finalize (PCR_FUSE_FINALIZE=0: k_reduce + k_finalize)
     uint32_t *d_tile_ctr = nullptr;     // per-XCD dynamic tile counters of k_nn_scan
     int nn_blocks_per_cu[2] = {4, 4};   // resident 256-thread blocks per CU of k_nn_scan<0/1>
@@ -127,8 +154,9 @@ struct pcr_target {
     uint32_t *cell_seed = nullptr;
     // point targets
     Geom<float> gf;
-    PtF *pts = nullptr;        // cell-sorted
-    float4 *normals = nullptr; // cell-sorted, w unused
+    PtF *pts = nullptr;        // cell-sorted (the NN search reads these 16-byte records)
+    PtN *pn = nullptr;         // cell-sorted point + normal records (PlaneICP gathers these); NULL = no normals
+    uint64_t serial = 0;
     // voxel targets
     Geom<double> gd;
     PtD *means = nullptr;      // cell-sorted
@@ -144,19 +172,27 @@ struct pcr_scan {
     pcr_context *ctx = nullptr;
     int64_t n = 0;
     float *x = nullptr, *y = nullptr, *z = nullptr;   // SoA, Morton-sorted unless PCR_FLAG_NO_SCAN_SORT
+    // matched cell-sorted index per scan point (PCR_NONE = gated out), written by k_nn_scan and read
+    // by the reduce kernel; kept across passes: the previous match is an exact upper bound for the
+    // next search against the SAME target (nn_serial)
+    uint32_t *nn_j = nullptr;
+    uint64_t nn_serial = 0;
 };
 
 // ---- index_build.hip
 pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n, float cell_hint, pcr_target *t);
 pcr_status pcr_build_centroid_grid(pcr_context *ctx, const double *d_mean, int64_t n, double cell, pcr_target *t);
+pcr_status pcr_count_nonfinite(pcr_context *ctx, const void *d_xyz, int is_f64, int64_t n, int64_t *count);
 pcr_status pcr_sort_scan(pcr_context *ctx, const float *d_xyz, int64_t n, unsigned flags, pcr_scan *s);
-pcr_status pcr_permute_rows_f32(pcr_context *ctx, const float *d_in, int64_t n, int width, const PtF *pts, float4 *out);
+pcr_status pcr_permute_normals(pcr_context *ctx, const float *d_in, int64_t n, const PtF *pts, PtN *out);
 pcr_status pcr_permute_rows_f64(pcr_context *ctx, const double *d_in, int64_t n, int in_stride, const int *cols,
                                 int ncols, const PtD *means, double *out);
 
 // ---- kernels.hip
 pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double T[16], double max_dist,
                              unsigned flags, double out[29]);
+pcr_status pcr_run_align(pcr_target *t, pcr_scan *s, int kind, const double T_init[16], int max_iter, double tol,
+                         double max_dist, unsigned flags, double T_out[16], int *iterations, double *trace_or_null);
 pcr_status pcr_run_nn(pcr_target *t, const float *d_q, int64_t m, double r_max, void *d_dist, int64_t *d_idx, int f64);
 pcr_status pcr_ensure_scratch(pcr_context *ctx, int64_t n_points);
 

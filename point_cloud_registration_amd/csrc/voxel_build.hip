@@ -168,8 +168,14 @@ extern "C" pcr_status pcr_target_voxels_create(pcr_context *ctx, const void *xyz
         HIP_TRY(hipMemcpyAsync(d_xyz.p, xyz, elem * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
+    int64_t nonfinite = 0;
+    PCR_TRY(pcr_count_nonfinite(ctx, d_xyz.p, xyz_is_f64, n, &nonfinite));
+    if (nonfinite > 0) {               // floor(NaN / voxel_size).astype(int64) is undefined in the reference as well
+        pcr_set_error("cloud has %lld point(s) with a non-finite coordinate; drop them first", (long long)nonfinite);
+        return PCR_ERR_INVALID;
+    }
     pcr_target *t = new pcr_target();
-    t->ctx = ctx; t->is_voxel = 1;
+    t->ctx = ctx; t->is_voxel = 1; t->serial = ctx->next_serial++;
     pcr_status s = xyz_is_f64 ? voxel_build<double>(ctx, (const double *)d_xyz.p, n, voxel_size, min_points, t)
                               : voxel_build<float>(ctx, (const float *)d_xyz.p, n, voxel_size, min_points, t);
     d_xyz.reset();

@@ -20,22 +20,22 @@ class PlaneICP(Registration):
     def set_target(self, target, kdree=None, norm=None):
         """Target + per-point normals (plane_icp.py:19-28).
 
-        ``kdree`` keeps the reference's (misspelt) keyword.  If both a tree and normals are
-        given the normal estimation is skipped, as in the reference; a tree that is this
-        package's :class:`KDTree` over the same cloud is reused, any other object is ignored
-        and a GPU index is built (a foreign CPU tree cannot be searched from a HIP kernel).
+        ``kdree`` keeps the reference's (misspelt) keyword.  If both a tree and normals are given the
+        normal estimation is skipped, as in the reference.  The tree object itself is never searched or
+        modified: a foreign CPU tree cannot be searched from a HIP kernel, and this registration's
+        normals live in its own device index (built in a few milliseconds), so a tree the caller shares
+        with other registrations keeps its state.
         """
         target = np.asarray(target)
         self.target = target.astype(np.float32)
-        if isinstance(kdree, KDTree) and kdree.n == self.target.shape[0]:
-            self.kdtree = kdree
-        else:
-            self.kdtree = KDTree(self.target, device=self._device, _ctx=self._ctx())
+        self.kdtree = KDTree(self.target, device=self._device, _ctx=self._ctx())
         if kdree is None or norm is None:
             # k-NN PCA normals on the GPU (estimate_normals.py:27-87)
             self.normal = self.kdtree._target.estimate_normals(self.k, compat=self._compat_normals)
         else:
             self.normal = np.asarray(norm)
+            if self.normal.shape != self.target.shape:
+                raise ValueError("norm must have the shape of the target")
             self.kdtree._target.set_normals(self.normal)
         self._target = self.kdtree._target
         self._is_target_set = True

@@ -11,11 +11,21 @@ Additions (none changes a default):
 * ``device=`` -- which GPU this process drives (default ``LOCAL_RANK``);
 * ``comm=`` -- a :class:`distributed.Communicator`; the scan passed to ``align`` is then this
   rank's SHARD and every ``calc_H_g_e2`` returns the sum over all ranks (SURVEY.md section 8e);
-* ``native_loop=True`` -- run the whole loop behind the C ABI (``pcr_align``), no Python per
-  iteration.
+* ``native_loop`` (default True) -- ``align`` runs the whole loop behind the C ABI (``pcr_align``):
+  pose in HBM, solve + boxplus in the last block of the reduce kernel, iterations enqueued back to
+  back, one result read by the host.  ``native_loop=False`` keeps the Python loop of the reference
+  (one ``calc_H_g_e2`` + ``numpy.linalg.solve`` per iteration), which ``verbose=True`` also uses
+  (it prints the reference's line before every solve).
 """
 
+import zlib
+
 import numpy as np
+
+try:                                   # fast non-cryptographic hash of the scan buffer (see _scan_for)
+    import xxhash as _xxhash
+except ImportError:                    # pragma: no cover
+    _xxhash = None
 
 from . import _capi
 from .math_tools import plus
@@ -24,7 +34,7 @@ from .math_tools import plus
 class Registration:
     KIND = None           # _capi.ICP / PLANE / VPLANE / NDT in the subclasses
 
-    def __init__(self, max_iter=30, tol=1e-3, device=None, comm=None, native_loop=False,
+    def __init__(self, max_iter=30, tol=1e-3, device=None, comm=None, native_loop=True,
                  compat_flags=_capi.FLAG_ICP_RR_QUIRK):
         self.max_iter = max_iter
         self.tol = tol
@@ -69,9 +79,11 @@ class Registration:
         scan = self._scan_for(np.asarray(source), fresh=True)     # the reference copies the scan per call
         cur_T = np.array(init_T, dtype=np.float64)
         if self._native_loop and not verbose and not self._needs_host_reduce():
-            T, iters = _capi.align(self._target, scan, self.KIND, cur_T, self.max_iter, self.tol,
-                                   self._max_dist(), self._flags)
+            T, iters, trace = _capi.align(self._target, scan, self.KIND, cur_T, self.max_iter, self.tol,
+                                          self._max_dist(), self._call_flags(), want_trace=True)
             self.last_iterations = iters
+            if iters:
+                self.last_correspondences = int(round(trace[iters - 1, 16 + 28]))
             return T
         it = 0
         for it in range(self.max_iter):
@@ -97,28 +109,44 @@ class Registration:
     def _needs_host_reduce(self):
         return self._comm is not None and not self._comm.in_library
 
+    def _call_flags(self):
+        """The collective is a per-call decision: only a Registration that was given ``comm=`` joins the
+        all-reduce, whatever else shares the (process-wide) context."""
+        if self._comm is not None and self._comm.in_library:
+            return self._flags
+        return self._flags | _capi.FLAG_LOCAL_ONLY
+
+    @staticmethod
+    def _digest(src):
+        """Hash of the WHOLE scan buffer (xxh3: ~1 ms per 1e6 float32 points; crc32 otherwise)."""
+        if src.size == 0:
+            return 0
+        buf = src if src.flags.c_contiguous else np.ascontiguousarray(src)
+        mv = memoryview(buf).cast("B")
+        if _xxhash is not None:
+            return _xxhash.xxh3_64_intdigest(mv)
+        return zlib.crc32(mv)
+
     def _scan_for(self, source, fresh=False):
         """Upload (and Morton-sort) the scan; ``calc_H_g_e2`` called repeatedly with the same array
-        (the Gauss-Newton pattern) reuses the device copy.  "Same" = same object, same buffer, same
-        shape and an unchanged fingerprint of 257 evenly spaced points -- an in-place edit that misses
-        all of them is not detected; ``align`` always uploads afresh."""
+        (the Gauss-Newton pattern) reuses the device copy.  "Same" = same shape, dtype and content:
+        the whole buffer is hashed on every call, so an in-place edit is always seen
+        (``calc_H_g_e2`` stays pure in its inputs, as in the reference); ``align`` always uploads
+        afresh."""
         src = np.asarray(source)
         if src.ndim != 2 or src.shape[1] != 3:
             raise ValueError("source must have shape (N, 3)")
-        n = src.shape[0]
-        probe = src[:: max(n // 256, 1)].tobytes() if n else b""
-        key = (id(source), src.__array_interface__["data"][0], src.shape, src.dtype.str, hash(probe))
-        if not fresh and self._scan is not None and self._scan_key == key:
+        key = None if fresh else (src.shape, src.dtype.str, self._digest(src))
+        if key is not None and self._scan is not None and self._scan_key == key:
             return self._scan
         if self._scan is not None:
             self._scan.close()
         self._scan = _capi.Scan(self._ctx(), src.astype(np.float32, copy=False))   # registration.py:83
         self._scan_key = key
-        self._scan_src = source            # keep the array alive so id() stays unique
         return self._scan
 
     def _linearize(self, cur_T, scan):
-        out = _capi.linearize(self._target, scan, self.KIND, cur_T, self._max_dist(), self._flags)
+        out = _capi.linearize(self._target, scan, self.KIND, cur_T, self._max_dist(), self._call_flags())
         if self._needs_host_reduce():
             out = self._comm.allreduce(out)
         H, g, e2, cnt = _capi.unpack29(out)

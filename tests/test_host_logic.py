@@ -22,6 +22,10 @@ class _OracleBacked:
     """Mixin: replaces the two GPU touch points of Registration with the CPU oracle so the HOST
     logic (align loop, quirks Q3/Q4/Q7, solve, plus) can be exercised without a GPU."""
 
+    def __init__(self, *a, **kw):
+        kw.setdefault("native_loop", False)       # the Python loop: the device-resident one needs a GPU
+        super().__init__(*a, **kw)
+
     def _scan_for(self, source, fresh=False):
         return np.ascontiguousarray(source, dtype=np.float32)
 

@@ -2,7 +2,8 @@
 restated against this package: same fixture (seed 42, 100 random points, R = expSO3([0.1, 0.2, 0.3]),
 t = [0.5, -0.3, 0.2]), same assertion -- the vectorised ``calc_H_g_e2`` (here: the HIP kernels) equals
 the per-point loop ``calc_H_g_e2_no_parallel_ver`` to atol = 1e-3 at cur_T = I -- plus the cases those
-tests cannot see: a multi-voxel masked cloud and the reference's own numbers."""
+tests cannot see: a multi-voxel masked cloud and the reference's own numbers.
+Every test runs once per kernel pipeline (conftest.PIPELINES); "default" is the shipped one."""
 
 import numpy as np
 import pytest
@@ -30,7 +31,7 @@ def _compare(obj, source, cur_T=np.eye(4), atol=1e-3):
     return H1, g1, e2_1
 
 
-def test_icp_calc_H_g_e2(generate_test_data, g1):
+def test_icp_calc_H_g_e2(generate_test_data, g1, pipeline):
     from point_cloud_registration_amd import ICP
     target, source = generate_test_data
     icp = ICP(max_iter=10, max_dist=2.0, tol=1e-3)
@@ -39,7 +40,7 @@ def test_icp_calc_H_g_e2(generate_test_data, g1):
     assert np.allclose(H, g1["I_icp_H"], atol=1e-3) and abs(e2 - g1["I_icp_e2"]) < 1e-4   # the reference's numbers
 
 
-def test_plane_icp_calc_H_g_e2(generate_test_data, g1):
+def test_plane_icp_calc_H_g_e2(generate_test_data, g1, pipeline):
     from point_cloud_registration_amd import PlaneICP
     target, source = generate_test_data
     picp = PlaneICP(max_iter=10, max_dist=2.0, tol=1e-3)
@@ -50,7 +51,7 @@ def test_plane_icp_calc_H_g_e2(generate_test_data, g1):
     assert np.allclose(H, g1["I_plane_H"], atol=1e-3) and abs(e2 - g1["I_plane_e2"]) < 1e-4
 
 
-def test_vplane_icp_calc_H_g_e2(generate_test_data, g1):
+def test_vplane_icp_calc_H_g_e2(generate_test_data, g1, pipeline):
     from point_cloud_registration_amd import VPlaneICP
     target, source = generate_test_data
     vp = VPlaneICP(voxel_size=1.0, max_iter=10, max_dist=2.0, tol=1e-3)
@@ -59,7 +60,7 @@ def test_vplane_icp_calc_H_g_e2(generate_test_data, g1):
     assert np.allclose(H, g1["I_vplane_H"], atol=1e-3) and abs(e2 - g1["I_vplane_e2"]) < 1e-4
 
 
-def test_ndt_calc_H_g_e2(generate_test_data, g1):
+def test_ndt_calc_H_g_e2(generate_test_data, g1, pipeline):
     from point_cloud_registration_amd import NDT
     target, source = generate_test_data
     ndt = NDT(voxel_size=1.0, max_iter=10, max_dist=2.0, tol=1e-3)
@@ -69,7 +70,7 @@ def test_ndt_calc_H_g_e2(generate_test_data, g1):
 
 
 @pytest.mark.parametrize("name", ["plane", "vplane", "ndt"])
-def test_loop_equals_kernels_on_masked_multivoxel_cloud(g2, name):
+def test_loop_equals_kernels_on_masked_multivoxel_cloud(g2, name, pipeline):
     """What the reference's tests cannot exercise: several voxels, ~10 % of the scan gated out, R != I."""
     import point_cloud_registration_amd as pcr
     md, vs = float(g2["max_dist"]), float(g2["voxel_size"])

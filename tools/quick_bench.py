@@ -49,5 +49,5 @@ for cell in [float(c) for c in a.cells.split(",")]:
             ks = " ".join(f"{k}={v[1]/max(v[0],1):.3f}ms" for k, v in prof.items() if v[0])
             print(f"  {kind_name} variant={variant}: wall {wall:.3f} ms/iter  corr={int(out[28])}  "
                   f"{scan.shape[0]/wall/1e3:.1f} Mcorr/s | {ks}", flush=True)
-    ctx.set_variant(0)
+    ctx.set_variant(1)
     tgt.close(); sc.close()
