@@ -12,8 +12,15 @@ Default workload = BASELINE.json configs[1]: Point-to-Plane ICP, B-01 stand-in t
 perturbed full-size scan; steps walk along a recorded Gauss-Newton trajectory.
 
 Multi-GPU (``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...``): one
-process per GPU, the target replicated, every rank owns a scan shard of the SAME size (weak
-scaling), no data-path collective besides the 232-byte all-reduce.
+process per GPU, the target replicated, no data-path collective besides the 232-byte all-reduce.
+``--scaling weak`` (default): every rank owns a scan shard of the SAME size (its own perturbed scan);
+``--scaling strong``: ONE scan of the configured size, rank r takes ``shard_scan(scan, r, N)``.
+
+Timing: ``--repeats R`` (default 5) timed blocks of exactly ``--steps`` passes each, every block
+bracketed by barrier + synchronize on both sides, max over ranks; ``ms_per_step`` / ``value`` are the
+MEDIAN block, min / max and all blocks are reported beside it.  HIP events bracket every 3rd pass of
+those blocks (an event pair costs microseconds of stream time); one further block with the events off
+is reported as ``ms_per_step_events_off``.
 
 Rank 0 prints one JSON line (contract in the task statement) with ``roofline`` (HIP-event kernel
 time measured here, live) and ``cpu_baseline`` (the CPU oracle on this box's host cores, bounded
@@ -21,6 +28,7 @@ sample, N = 1 only).
 """
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -62,7 +70,21 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-passes", type=int, default=3)
     ap.add_argument("--variant", type=int, default=None, help="0 fused kernel, 1 NN + reduce kernels")
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps passes; the median is reported")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--event-period", type=int, default=3, help="HIP events around every n-th pass")
     return ap.parse_args()
+
+
+def kernel_source_hash():
+    """Identity of the kernels a PMC profile was collected on: sha1 over the HIP sources."""
+    h = hashlib.sha1()
+    d = os.path.join(REPO, "point_cloud_registration_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def make_cloud(n, seed):
@@ -121,12 +143,17 @@ def main():
         data_tag = "B-01.pcd"
     else:
         target = make_cloud(n_target, seed=0)
+    strong = args.scaling == "strong"
+    sseed = 0 if strong else rank                              # strong: every rank builds the SAME scan, keeps a shard
     if "harness" in args.config:
-        scan = harness_scan(target, n_scan, seed=1 + rank)
+        scan = harness_scan(target, n_scan, seed=1 + sseed)
         T_true = np.eye(4)
         T_true[2, 3] = -0.3                                   # align(scan, I) undoes the +0.3 m shift
     else:
-        scan, T_true = perturbed_scan(target, n_scan if n_scan < n_target else None, seed=2 + rank)
+        scan, T_true = perturbed_scan(target, n_scan if n_scan < n_target else None, seed=2 + sseed)
+    n_scan_job = scan.shape[0] if strong else scan.shape[0] * world
+    if strong:
+        scan = np.ascontiguousarray(pdist.shard_scan(scan, rank, world))
     if kind_name in ("icp", "plane"):
         tgt = _capi.Target.points(ctx, target)
         if kind_name == "plane":
@@ -162,41 +189,65 @@ def main():
     import gc
     gc.collect()
     gc.disable()
-    ctx.profile_enable(True)
+
+    def timed_block():
+        """EXACTLY args.steps passes, barrier + synchronize on both sides, max over ranks."""
+        sync_all()
+        t0 = time.perf_counter()
+        o = None
+        for k in range(args.steps):
+            o = step(k)
+        sync_all()
+        dt = time.perf_counter() - t0
+        if use_comm:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, o
+
+    ctx.profile_enable(True, period=args.event_period)
     ctx.profile_reset()
-    sync_all()
-    t0 = time.perf_counter()
+    blocks = []
     out = None
-    step_t = []
-    for k in range(args.steps):
-        ts = time.perf_counter()
-        out = step(k)
-        step_t.append(time.perf_counter() - ts)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
+    for r in range(max(args.repeats, 1)):
+        dt, out = timed_block()
+        blocks.append(dt)
     prof = ctx.profile_read()
     ctx.profile_enable(False)
-    if use_comm:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    t_noev, _ = timed_block()                                  # the same block with the events off
+    gc.enable()
+    elapsed = float(np.median(blocks))
+    step_t = [b / args.steps for b in blocks]
 
-    if os.environ.get("PCR_BENCH_DEBUG"):
-        print("per-step ms:", " ".join(f"{t * 1e3:.2f}" for t in step_t), file=sys.stderr)
+    per_rank = None
+    if use_comm:                                                # every rank's own kernel / all-reduce times
+        mine = {k: round(v[1] / v[0], 5) for k, v in prof.items() if v[0]}
+        per_rank = [None] * world
+        torch.distributed.all_gather_object(per_rank, mine)
     if rank == 0:
-        units = world * sc.n * args.steps                   # correspondences searched, whole job
+        units = n_scan_job * args.steps                     # correspondences searched, whole job
         value = units / elapsed / 1e6
         kern = {k: {"launches": v[0], "avg_ms": v[1] / v[0]} for k, v in prof.items() if v[0]}
         # dominant kernel(s) of one pass: everything that touches the scan / target
         hot_ms = sum(kern[k]["avg_ms"] for k in ("linearize", "nn", "reduce") if k in kern)
         alg_bytes = B_ALG[kind_name] * sc.n                 # per launch (one pass over this rank's shard)
         achieved = alg_bytes / (hot_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM traffic per pass from the PMC passes of the SAME command (profiles/pmc_summary.json, collected
+        # as MI355X_MICROARCH.md prescribes: separate --pmc runs, FETCH_SIZE x2); only trusted when that
+        # profile was taken on these very kernels (hash of the HIP sources), otherwise null
+        traffic, traffic_src = None, None
         pmc_file = os.path.join(REPO, "profiles", "pmc_summary.json")
         if os.path.exists(pmc_file):
             try:
-                traffic = json.load(open(pmc_file)).get(args.config, {}).get("hbm_bytes_per_pass")
+                pm = json.load(open(pmc_file))
+                entry = pm.get(args.config, {})
+                if pm.get("kernel_source_hash") == kernel_source_hash():
+                    traffic = entry.get("hbm_bytes_per_pass")
+                    traffic_src = {"file": "profiles/pmc_summary.json", "collected_at_commit": pm.get("commit"),
+                                   "kernel_source_hash": pm.get("kernel_source_hash"), "raw": entry.get("source")}
+                else:
+                    traffic_src = {"file": "profiles/pmc_summary.json", "stale": True,
+                                   "note": "PMC profile predates the current kernels; traffic withheld"}
             except Exception:
                 traffic = None
         line = {
@@ -206,16 +257,20 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "iterations_per_sec": round(args.steps / elapsed, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step_min": round(min(step_t) * 1e3, 4), "ms_per_step_max": round(max(step_t) * 1e3, 4),
+            "repeat_ms_per_step": [round(t * 1e3, 4) for t in step_t], "repeats": len(blocks),
+            "ms_per_step_events_off": round(t_noev / args.steps * 1e3, 4), "event_period": args.event_period,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "accumulate_dtype": "f64", "data": data_tag,
             "config": {"workload": args.config, "description": desc, "kind": kind_name,
                        "target_points": int(n_target), "scan_points_per_gpu": int(sc.n),
                        "max_dist": max_dist, "voxel_size": voxel_size, "parallelism": f"scan-shard x{world}",
+                       "scan_points_job": int(n_scan_job),
                        "nn_index": {"cell": info["cell"], "dims": info["dims"], "occupied_cells": info["occupied"]},
                        "gauss_newton_iters_to_converge": iters, "pose_error_m": round(pose_err, 6),
                        "correspondences_last_step": int(out[28]), "setup_s": round(t_setup, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "+".join(k for k in ("linearize", "nn", "reduce") if k in kern),
                          "kernel_ms": round(hot_ms, 5), "algorithmic_bytes_per_launch": int(alg_bytes),
                          "bytes_per_point": B_ALG[kind_name]},
@@ -228,6 +283,8 @@ def main():
                                               "unit": "GB/s", "frac": round(k2 / HBM_PEAK_GBS, 6),
                                               "bytes_per_point": B_ALG[kind_name] + 4,
                                               "kernel_ms": round(kern["reduce"]["avg_ms"], 5)}
+        if per_rank is not None:
+            line["per_rank_kernel_ms"] = per_rank
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(kind_name, target, scan, tgt, traj, max_dist, voxel_size,
                                                 args.cpu_passes)

@@ -167,7 +167,9 @@ PCR_API pcr_status pcr_knn_query(pcr_target *t, const float *q, int64_t m, int k
 /* ---- instrumentation ------------------------------------------------------------------
  * With profiling on, every launch of a hot-path kernel is bracketed by HIP events on the
  * context's stream; pcr_profile_read drains them (synchronises) and reports per-kernel
- * launch count and total milliseconds since the last reset.                                */
+ * launch count and total milliseconds since the last reset.  on = n > 1 brackets only every
+ * n-th pass (an event pair costs a few microseconds of stream time: sampling keeps a timed
+ * region honest); on = 1 every pass; 0 off.                                                 */
 enum { PCR_K_LINEARIZE = 0, PCR_K_FINALIZE = 1, PCR_K_NN = 2, PCR_K_REDUCE = 3, PCR_K_ALLREDUCE = 4, PCR_K_COUNT = 5 };
 PCR_API pcr_status pcr_profile_enable(pcr_context *ctx, int on);
 PCR_API pcr_status pcr_profile_reset(pcr_context *ctx);

@@ -12,7 +12,8 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpcr_hip.so")
+# PCR_LIB: developer switch, an experimental build of the same library (tools/build_variant.sh)
+LIB_PATH = os.environ.get("PCR_LIB") or os.path.join(_HERE, "libpcr_hip.so")
 
 PCR_OK = 0
 PCR_ERR_INVALID, PCR_ERR_HIP, PCR_ERR_NO_TARGET, PCR_ERR_COMM, PCR_ERR_SINGULAR, PCR_ERR_NOMEM = -1, -2, -3, -4, -5, -6
@@ -237,8 +238,9 @@ class Context:
         self.nranks, self.rank = 1, 0
 
     # -- profiling
-    def profile_enable(self, on=True):
-        check(lib().pcr_profile_enable(self.handle, int(bool(on))))
+    def profile_enable(self, on=True, period=1):
+        """HIP events around the hot-path launches; ``period`` = n brackets every n-th pass only."""
+        check(lib().pcr_profile_enable(self.handle, (max(int(period), 1) if on else 0)))
 
     def profile_reset(self):
         check(lib().pcr_profile_reset(self.handle))

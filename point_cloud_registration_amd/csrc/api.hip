@@ -130,7 +130,7 @@ extern "C" pcr_status pcr_set_nn_mode(pcr_context *ctx, int mode) {
 // ---- profiling: HIP events around every hot-path launch, on the launch stream ------------------
 void pcr_prof_begin(pcr_context *ctx, int kernel, ProfEvent *ev) {
     ev->kernel = -1;
-    if (!ctx->prof_on) return;
+    if (!ctx->prof_on || !ctx->prof_this_pass) return;
     if (!ctx->prof_free.empty()) {
         *ev = ctx->prof_free.back();
         ctx->prof_free.pop_back();
@@ -165,6 +165,9 @@ extern "C" pcr_status pcr_profile_enable(pcr_context *ctx, int on) {
     PCR_REQUIRE(ctx, "ctx is NULL");
     if (!on) prof_drain(ctx);
     ctx->prof_on = on != 0;
+    ctx->prof_period = on > 1 ? on : 1;        // on = n > 1: events around every n-th pass only (sampling)
+    ctx->prof_pass = 0;
+    ctx->prof_this_pass = ctx->prof_on;
     return PCR_OK;
 }
 

@@ -195,6 +195,55 @@ __device__ __forceinline__ void accumulate(double *acc, const LinArgs &a, const 
     }
 }
 
+// The streaming loop of the reduce kernels.  Point targets: the matched records of TWO scan points are
+// gathered before either is accumulated (two independent 16/32-byte gathers in flight per lane: at
+// 1e8 target points every gather is an HBM miss and the kernel is bound by misses in flight); the
+// points are still accumulated in index order, so the sums are bit-identical to the one-at-a-time loop.
+template <int KIND>
+__device__ __forceinline__ void reduce_stream(double *acc, const LinArgs &a, const PoseK &P, int64_t base, int64_t end,
+                                              int64_t stride) {
+    if (KIND == PCR_ICP || KIND == PCR_PLANE) {
+        for (int64_t i = base; i < end; i += 2 * stride) {
+            const int64_t i1 = i + stride;
+            const bool two = i1 < end;
+            const uint32_t j0 = a.nn_j[i];
+            const uint32_t j1 = two ? a.nn_j[i1] : PCR_NONE;
+            const bool ok0 = j0 != PCR_NONE, ok1 = j1 != PCR_NONE;
+            float4 q0 = make_float4(0, 0, 0, 0), n0 = q0, q1 = q0, n1 = q0;
+            if (KIND == PCR_PLANE) {
+                if (ok0) { const float4 *r = reinterpret_cast<const float4 *>(a.pn + j0); q0 = r[0]; n0 = r[1]; }
+                if (ok1) { const float4 *r = reinterpret_cast<const float4 *>(a.pn + j1); q1 = r[0]; n1 = r[1]; }
+            } else {
+                if (ok0) q0 = a.pts[j0];
+                if (ok1) q1 = a.pts[j1];
+            }
+            if (ok0) {
+                const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
+                float tx, ty, tz;
+                xform(P, x, y, z, tx, ty, tz);
+                if (KIND == PCR_PLANE) acc_plane(acc, P, x, y, z, n0.x, n0.y, n0.z, (double)(tx - q0.x), (double)(ty - q0.y), (double)(tz - q0.z));
+                else acc_icp(acc, P, a.flags, x, y, z, (double)(tx - q0.x), (double)(ty - q0.y), (double)(tz - q0.z));
+            }
+            if (ok1) {
+                const float x = a.sx[i1], y = a.sy[i1], z = a.sz[i1];
+                float tx, ty, tz;
+                xform(P, x, y, z, tx, ty, tz);
+                if (KIND == PCR_PLANE) acc_plane(acc, P, x, y, z, n1.x, n1.y, n1.z, (double)(tx - q1.x), (double)(ty - q1.y), (double)(tz - q1.z));
+                else acc_icp(acc, P, a.flags, x, y, z, (double)(tx - q1.x), (double)(ty - q1.y), (double)(tz - q1.z));
+            }
+        }
+    } else {
+        for (int64_t i = base; i < end; i += stride) {
+            const uint32_t j = a.nn_j[i];
+            if (j == PCR_NONE) continue;
+            const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
+            float tx, ty, tz;
+            xform(P, x, y, z, tx, ty, tz);
+            accumulate<KIND>(acc, a, P, j, x, y, z, tx, ty, tz);
+        }
+    }
+}
+
 // ---- block reduction of 32 float64 sums --------------------------------------------------
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -297,19 +346,73 @@ __global__ void __launch_bounds__(256) k_linearize(const LinArgs a) {
 // SEED: the match of the PREVIOUS pass over this scan against this target (still in nn_j) starts
 // the search: any real target point is an exact upper bound, so only cells inside that radius are
 // looked at (the result is the same exact nearest neighbour).
+// developer ablations for timing studies (results are WRONG when set; never in a shipped build):
+//   PCR_NN_ABLATE 1 = no search at all, 2 = own cell only;  PCR_NN_STATIC 1 = round-robin tiles, no counters
+#ifndef PCR_NN_ABLATE
+#define PCR_NN_ABLATE 0
+#endif
+#ifndef PCR_NN_STATIC
+#define PCR_NN_STATIC 0
+#endif
+// Tile hand-out.  The sorted scan is cut into PCR_TILE_CTRS contiguous sub-spans; sub-spans c, c + 8,
+// c + 16, ... belong to XCD c & 7 (blocks b with b % 8 == c run there: a locality assumption only).
+// A wave's first PCR_TILE_STATIC_ROUNDS tiles of its home sub-span are fixed by its index (no atomic:
+// thousands of waves asking the same word at launch serialise at ~30 ns each), the rest of every
+// sub-span is handed out by a counter; a wave that finds its home sub-span empty moves on to the
+// other sub-spans of its XCD.  Counters live PCR_TILE_STRIDE words apart.
+#ifndef PCR_TILE_CTRS
+#define PCR_TILE_CTRS 64       // measured on MI355X (1.06 M queries, skeleton without the search): 8 counters
+#endif                         // and no static round 64 us, 8 + static 45, 64: 34, 64 + static 31, no counters 7
+#ifndef PCR_TILE_STRIDE
+#define PCR_TILE_STRIDE 16
+#endif
+#ifndef PCR_TILE_STATIC_ROUNDS
+#define PCR_TILE_STATIC_ROUNDS 1   // 2 static rounds already unbalance the far poses (whole kernel 127 -> 155 us)
+#endif
+#define PCR_TILE_SUB (PCR_TILE_CTRS / 8)
 template <int VOXEL, int SEED>
 __global__ void __launch_bounds__(256) k_nn_scan(const LinArgs a) {
     PoseK P;
     if (!load_pose<false>(a, P)) return;
     const int xcd = (int)(blockIdx.x & 7);
-    const int64_t span = (((a.n + 7) >> 3) + 63) & ~(int64_t)63;
-    const int64_t lo = span * xcd;
-    const int64_t end = lo + span < a.n ? lo + span : a.n;
     const int lane = threadIdx.x & 63;
-    for (;;) {
-        uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(&a.tile_ctr[xcd * 16], 1u);
-        t = __builtin_amdgcn_readfirstlane(t);
+    const int64_t span = (((a.n + PCR_TILE_CTRS - 1) / PCR_TILE_CTRS) + 63) & ~(int64_t)63;
+    // waves of this XCD that call sub-span `home` their home, and this wave's rank among them
+    const uint32_t xb = blockIdx.x >> 3, nxb = gridDim.x >> 3;                 // block index / blocks on this XCD
+    const int home = (int)(xb % PCR_TILE_SUB);
+    const uint32_t wrank = (xb / PCR_TILE_SUB) * 4 + (threadIdx.x >> 6);
+    const uint32_t wcount = ((nxb - home + PCR_TILE_SUB - 1) / PCR_TILE_SUB) * 4;
+#if PCR_NN_STATIC
+    const int sub = home;
+    const int c = xcd + 8 * sub;
+    const int64_t lo = span * c;
+    const int64_t end = lo + span < a.n ? lo + span : a.n;
+    uint32_t t = wrank;
+    for (;; t += wcount) {
+        {
+#else
+    for (int r = 0; r < PCR_TILE_SUB; ++r) {
+        const int sub = (home + r) % PCR_TILE_SUB;
+        const int c = xcd + 8 * sub;
+        const int64_t lo = span * c;
+        const int64_t end = lo + span < a.n ? lo + span : a.n;
+        // static tiles of sub-span `sub`: PCR_TILE_STATIC_ROUNDS per home wave of that sub-span
+        const uint32_t hcount = ((nxb - sub + PCR_TILE_SUB - 1) / PCR_TILE_SUB) * 4;
+        const uint32_t nstatic = PCR_TILE_STATIC_ROUNDS * hcount;
+        int sr = r == 0 ? 0 : PCR_TILE_STATIC_ROUNDS;          // static rounds only at home
+        const uint32_t ntiles = end > lo ? (uint32_t)((end - lo + 63) >> 6) : 0u;
+        for (;;) {
+            uint32_t t = 0;
+            // every tile of this sub-span is a static one (small scans): no counter to ask
+            if (sr >= PCR_TILE_STATIC_ROUNDS && nstatic >= ntiles) break;
+            if (sr < PCR_TILE_STATIC_ROUNDS) {
+                t = wrank + (uint32_t)sr * wcount;
+                ++sr;
+            } else {
+                if (lane == 0) t = atomicAdd(&a.tile_ctr[c * PCR_TILE_STRIDE], 1u);
+                t = __builtin_amdgcn_readfirstlane(t) + nstatic;
+            }
+#endif
         const int64_t i = lo + (int64_t)t * 64 + lane;
         if (lo + (int64_t)t * 64 >= end) break;
         if (i >= end) continue;
@@ -322,8 +425,15 @@ __global__ void __launch_bounds__(256) k_nn_scan(const LinArgs a) {
         bool ok;
         if (!VOXEL) {
             float best = a.bound2_f;
+#if PCR_NN_ABLATE == 1
+            bj = __float_as_uint(tx + ty + tz) & 0xffffu; best = 0.f;
+#elif PCR_NN_ABLATE == 2
+            { const NNCell<float> c = nn_cell<float>(a.gf, tx, ty, tz, a.bound2_f);
+              (void)nn_ring0<float, PtF>(a.gf, a.pts, a.cell_start, c, tx, ty, tz, best, bj, bo); }
+#else
             if (SEED && pj != PCR_NONE) nn_test<float, PtF>(a.pts[pj], pj, tx, ty, tz, best, bj, bo);
             nn_search<float, PtF, false, true>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
+#endif
             ok = bj != PCR_NONE && __builtin_sqrtf(best) < a.md_f;
         } else {
             double best = a.bound2_d;
@@ -332,6 +442,7 @@ __global__ void __launch_bounds__(256) k_nn_scan(const LinArgs a) {
             ok = bj != PCR_NONE && __builtin_sqrt(best) < a.md_d;
         }
         a.nn_j[i] = ok ? bj : PCR_NONE;
+        }
     }
 }
 
@@ -380,7 +491,8 @@ __global__ void __launch_bounds__(256) k_nn_counters(const LinArgs a, unsigned l
 // ---- fold the per-block partials in a fixed order and emit the 29-vector ---------------------
 struct FinArgs {
     const double *partials;
-    uint32_t *tile_ctr;        // 64 B apart: [0..7] tile counters, [8..15] group tickets, [16] leader tickets
+    uint32_t *tile_ctr;        // the PCR_TILE_CTRS tile counters of k_nn_scan (re-armed by the fold)
+    uint32_t *tickets;         // 64 B apart: [0..7] group tickets, [8] leader tickets
     int nblocks;
     int kind;
     double R[9];               // rotation of the pose when it came by value (pose == NULL)
@@ -390,7 +502,6 @@ struct FinArgs {
     uint32_t seq;
     // device-resident Gauss-Newton loop (pcr_align; registration.py:89-111 behind the boundary)
     PoseDev *pose;             // NULL: plain pass
-    int gn_inline;             // 1: solve + boxplus right after the fold; 0: k_gn_update does it after the all-reduce
     int max_iter;
     double tol;
     double *trace;             // [max_iter][45]: pose before the step (16) + the 29 sums
@@ -401,7 +512,7 @@ struct FinArgs {
 // tot[0..31] (shared memory, complete before the call) -> the 29-vector in HBM and, optionally, in
 // pinned host memory followed by the sequence number; also re-arms the tile counters.
 __device__ __forceinline__ void finalize_emit(const FinArgs &f, const double *tot) {
-    if (threadIdx.x < 8) f.tile_ctr[threadIdx.x * 16] = 0;     // ready for the next k_nn_scan
+    if (threadIdx.x < PCR_TILE_CTRS) f.tile_ctr[threadIdx.x * PCR_TILE_STRIDE] = 0;     // ready for the next k_nn_scan
     if (threadIdx.x == 0) {
         if (f.kind != PCR_ICP) {
             for (int i = 0; i < 29; ++i) f.out[i] = tot[i];
@@ -470,7 +581,8 @@ __device__ __forceinline__ void gn_update(const FinArgs &f, double (*A)[7]) {
     }
 }
 
-// multi-GPU loop: the step after the all-reduce of the 29 sums (every rank computes the same update)
+// the step of the device-resident loop: a 1-wave launch behind the fold (single GPU) or behind the
+// all-reduce of the 29 sums (multi-GPU: every rank computes the same update)
 __global__ void __launch_bounds__(64) k_gn_update(const FinArgs f) {
     __shared__ double A[6][7];
     if (threadIdx.x == 0 && f.pose->done == PCR_LOOP_RUNNING) gn_update(f, A);
@@ -528,7 +640,6 @@ __device__ __forceinline__ void finalize_body(const FinArgs &f) {
     }
     __syncthreads();
     finalize_emit(f, tot);
-    if (f.pose && f.gn_inline && threadIdx.x == 0) gn_update(f, reinterpret_cast<double (*)[7]>(&part[0][0]));
 }
 
 __global__ void __launch_bounds__(1024) k_finalize(const FinArgs f) {
@@ -544,14 +655,7 @@ __global__ void __launch_bounds__(256) k_reduce(const LinArgs a) {
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = 0.0;
     const TileIter it(a);
-    for (int64_t i = it.base; i < it.end; i += it.stride) {
-        const uint32_t j = a.nn_j[i];
-        if (j == PCR_NONE) continue;
-        const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
-        float tx, ty, tz;
-        xform(P, x, y, z, tx, ty, tz);
-        accumulate<KIND>(acc, a, P, j, x, y, z, tx, ty, tz);
-    }
+    reduce_stream<KIND>(acc, a, P, it.base, it.end, it.stride);
     block_store_partials(acc, a.partials);
 }
 
@@ -570,21 +674,14 @@ __global__ void __launch_bounds__(256) k_reduce_finalize(const LinArgs a, const 
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = 0.0;
     const TileIter it(a);
-    for (int64_t i = it.base; i < it.end; i += it.stride) {
-        const uint32_t j = a.nn_j[i];
-        if (j == PCR_NONE) continue;
-        const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
-        float tx, ty, tz;
-        xform(P, x, y, z, tx, ty, tz);
-        accumulate<KIND>(acc, a, P, j, x, y, z, tx, ty, tz);
-    }
+    reduce_stream<KIND>(acc, a, P, it.base, it.end, it.stride);
     block_store_partials<true>(acc, a.partials);
 
     __shared__ int role;
     __shared__ double part[8][33];
     __shared__ double tot[32];
     const int g = (int)(blockIdx.x & 7), per = f.nblocks >> 3;
-    uint32_t *ctr1 = &f.tile_ctr[(8 + g) * 16], *ctr2 = &f.tile_ctr[16 * 16];
+    uint32_t *ctr1 = &f.tickets[g * 16], *ctr2 = &f.tickets[8 * 16];
     double *rows = const_cast<double *>(f.partials);
     // Hand-off protocol (MI355X guide, "sc1 payload -> drained vmcnt -> sc1 flag"): the 32 partial sums
     // were stored write-through at agent scope by lanes 0..31 of THIS wave; the explicit s_waitcnt below
@@ -642,8 +739,8 @@ __global__ void __launch_bounds__(256) k_reduce_finalize(const LinArgs a, const 
     }
     __syncthreads();
     finalize_emit(f, tot);
-    // every other block has stored its partials, i.e. has long read the pose: safe to rewrite it
-    if (f.pose && f.gn_inline && threadIdx.x == 0) gn_update(f, reinterpret_cast<double (*)[7]>(&part[0][0]));
+    // (the Gauss-Newton step is NOT inlined here: its straight-line float64 code needs 136 VGPRs, which
+    // would cap this streaming kernel at 3 blocks per CU; k_gn_update runs it as a 1-wave launch)
 }
 
 // after the RCCL all-reduce: hand the 29 doubles to the host the same zero-copy way k_finalize does
@@ -685,8 +782,10 @@ pcr_status pcr_ensure_scratch(pcr_context *ctx, int64_t n_points) {
         HIP_TRY(hipHostMalloc(&ctx->h_out, sizeof(double) * 64, hipHostMallocMapped | hipHostMallocCoherent));
         memset(ctx->h_out, 0, sizeof(double) * 64);
         HIP_TRY(hipHostGetDevicePointer((void **)&ctx->h_out_dev, ctx->h_out, 0));
-        HIP_TRY(hipMalloc(&ctx->d_tile_ctr, sizeof(uint32_t) * 17 * 16));      // 8 tile counters + 8 + 1 tickets
-        HIP_TRY(hipMemsetAsync(ctx->d_tile_ctr, 0, sizeof(uint32_t) * 17 * 16, ctx->stream));
+        // 8 + 1 tickets (64 B apart), then the tile counters
+        const size_t ctr_words = 9 * 16 + (size_t)PCR_TILE_CTRS * PCR_TILE_STRIDE;
+        HIP_TRY(hipMalloc(&ctx->d_tile_ctr, sizeof(uint32_t) * ctr_words));
+        HIP_TRY(hipMemsetAsync(ctx->d_tile_ctr, 0, sizeof(uint32_t) * ctr_words, ctx->stream));
         for (int v = 0; v < 2; ++v) {
             int nb = 0;
             hipError_t e = v == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<0, 0>, 256, 0)
@@ -757,7 +856,7 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
     a.flags = flags;
     a.nblocks = choose_blocks(ctx, s->n);
     a.partials = ctx->d_partials;
-    a.nn_j = s->nn_j; a.tile_ctr = ctx->d_tile_ctr;
+    a.nn_j = s->nn_j; a.tile_ctr = ctx->d_tile_ctr + 9 * 16;
     if (ctx->variant == 1 && a.nblocks > ctx->num_cu * 4) a.nblocks = ctx->num_cu * 4;   // k_reduce streams: 4 blocks/CU
     // TileIter and the ticket counts of k_reduce_finalize need a multiple of 8 blocks
     a.nblocks &= ~7;
@@ -766,7 +865,7 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
     ps->seed = ctx->variant == 1 && ctx->nn_mode == 1 && s->nn_serial == t->serial && s->nn_serial != 0;
     FinArgs &f = ps->f;
     memset(&f, 0, sizeof f);
-    f.partials = ctx->d_partials; f.tile_ctr = ctx->d_tile_ctr; f.nblocks = a.nblocks; f.kind = kind; f.out = ctx->d_out;
+    f.partials = ctx->d_partials; f.tile_ctr = ctx->d_tile_ctr + 9 * 16; f.tickets = ctx->d_tile_ctr; f.nblocks = a.nblocks; f.kind = kind; f.out = ctx->d_out;
     return PCR_OK;
 }
 
@@ -793,6 +892,7 @@ static pcr_status pass_enqueue(Pass *ps) {
     const LinArgs &a = ps->a;
     const dim3 grid(a.nblocks), block(256);
     ProfEvent ev;
+    if (ctx->prof_on) ctx->prof_this_pass = (ctx->prof_pass++ % (uint64_t)ctx->prof_period) == 0;
     if (ctx->variant == 0) {
         pcr_prof_begin(ctx, PCR_K_LINEARIZE, &ev);
         switch (ps->kind) {
@@ -898,8 +998,8 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
 }
 
 // ---- Registration.align behind the boundary, device-resident (registration.py:71-113) -------------
-// The pose lives in HBM; every iteration is k_nn_scan + k_reduce_finalize whose last block also does
-// dx = -solve(H, g), the |dx| < tol test and T <- plus(T, dx) (gn_update).  The host only keeps the
+// The pose lives in HBM; every iteration is k_nn_scan + k_reduce_finalize + k_gn_update (one wave:
+// dx = -solve(H, g), the |dx| < tol test and T <- plus(T, dx)).  The host only keeps the
 // queue a couple of iterations ahead of the GPU and watches two words in pinned memory: no host round
 // trip, no device-to-host copy and no host solve between iterations.  Launches that arrive after
 // convergence see pose->done and return at once.  With a communicator the 29 sums are all-reduced
@@ -927,7 +1027,7 @@ pcr_status pcr_run_align(pcr_target *t, pcr_scan *s, int kind, const double T_in
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
     ps.a.pose = ctx->d_pose;
     FinArgs &f = ps.f;
-    f.pose = ctx->d_pose; f.gn_inline = use_comm ? 0 : 1; f.max_iter = max_iter; f.tol = tol;
+    f.pose = ctx->d_pose; f.max_iter = max_iter; f.tol = tol;
     f.trace = ctx->d_trace;
     f.host_T = ctx->h_out_dev + 40;
     f.host_state = (volatile unsigned long long *)(ctx->h_out_dev + 56);
@@ -945,7 +1045,13 @@ pcr_status pcr_run_align(pcr_target *t, pcr_scan *s, int kind, const double T_in
         for (;;) {
             if (loop_done() != PCR_LOOP_RUNNING) break;
             const int fin = passes_done();
-            if (enq < max_iter && enq < fin + AHEAD) { PCR_TRY(pass_enqueue(&ps)); ++enq; spin = 0; continue; }
+            if (enq < max_iter && enq < fin + AHEAD) {
+                PCR_TRY(pass_enqueue(&ps));
+                hipLaunchKernelGGL(k_gn_update, dim3(1), dim3(64), 0, ctx->stream, f);
+                HIP_TRY(hipGetLastError());
+                ++enq; spin = 0;
+                continue;
+            }
             __builtin_ia32_pause();
             if (++spin > 4000000L) {    // a very long pass (or a fault): block, then look again
                 HIP_TRY(hipStreamSynchronize(ctx->stream));

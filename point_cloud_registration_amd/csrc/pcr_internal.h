@@ -136,6 +136,9 @@ struct pcr_context {
     int nn_blocks_per_cu[2] = {4, 4};   // resident 256-thread blocks per CU of k_nn_scan<0/1>
     // profiling
     bool prof_on = false;
+    int prof_period = 1;        // events around every prof_period-th pass (1 = every pass)
+    uint64_t prof_pass = 0;     // passes enqueued since profiling was switched on
+    bool prof_this_pass = false;
     std::vector<ProfEvent> prof_events;
     std::vector<ProfEvent> prof_free;
     int64_t prof_launches[PCR_K_COUNT] = {0};

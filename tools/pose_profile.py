@@ -16,6 +16,9 @@ ap.add_argument("--config", default="plane_b01")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--modes", default="0,1")
 ap.add_argument("--align-reps", type=int, default=10)
+ap.add_argument("--save-traj", default=None)
+ap.add_argument("--load-traj", default=None, help="poses from a correct build (ablation builds give wrong sums)")
+ap.add_argument("--brief", action="store_true", help="per-pose sequence timings only")
 a = ap.parse_args()
 
 kind_name, n_target, n_scan, voxel_size, desc = B.CONFIGS[a.config]
@@ -35,14 +38,19 @@ if kind_name in ("icp", "plane"):
 else:
     tgt = _capi.Target.voxels(ctx, target, voxel_size, 10)
 sc = _capi.Scan(ctx, scan)
-T_fin, iters, trace = _capi.align(tgt, sc, kind, np.eye(4), 30, 1e-3, 2.0, want_trace=True)
-traj = [trace[i, :16].reshape(4, 4).copy() for i in range(iters)]
+if a.load_traj:
+    traj = list(np.load(a.load_traj)); iters = len(traj)
+else:
+    T_fin, iters, trace = _capi.align(tgt, sc, kind, np.eye(4), 30, 1e-3, 2.0, want_trace=True)
+    traj = [trace[i, :16].reshape(4, 4).copy() for i in range(iters)]
+if a.save_traj:
+    np.save(a.save_traj, np.array(traj))
 print(f"[{a.config}] {iters} GN iterations, index {tgt.index_info()}", flush=True)
 
 for mode in [int(m) for m in a.modes.split(",")]:
     ctx.set_nn_mode(mode)
     # (1) each pose on its own, repeated (seeded mode: seeded by the same pose's matches = best case)
-    for k, T in enumerate(traj):
+    for k, T in enumerate([] if a.brief else traj):
         _capi.linearize(tgt, sc, kind, T, 2.0)
         ctx.profile_enable(True); ctx.profile_reset()
         t0 = time.perf_counter()
@@ -64,6 +72,8 @@ for mode in [int(m) for m in a.modes.split(",")]:
     for k in range(len(traj)):
         print(f"  mode {mode} pose {k} in sequence: nn={per[k, 0] / cnt[k] * 1e3:.1f}us reduce={per[k, 1] / cnt[k] * 1e3:.1f}us", flush=True)
     print(f"  mode {mode} trajectory mean: nn={per[:, 0].sum() / cnt.sum() * 1e3:.1f}us reduce={per[:, 1].sum() / cnt.sum() * 1e3:.1f}us", flush=True)
+    if a.brief:
+        continue
     # (3) unprofiled wall per pass, trajectory walk (what bench.py reports)
     import gc; gc.collect(); gc.disable()
     for k in range(5):
