@@ -157,7 +157,10 @@ def main():
     if kind_name in ("icp", "plane"):
         tgt = _capi.Target.points(ctx, target)
         if kind_name == "plane":
-            tgt.estimate_normals(15, compat=True, want=False)      # reference default k=15 (plane_icp.py:14)
+            # reference default k=15 (plane_icp.py:14).  The reference's float32 single-pass covariance
+            # (estimate_normals.py:56-72) is kept where it works (|p| <= 60 m); at the 100 M cloud's
+            # |p| ~ 600 m it loses every digit, so that config uses the centred float64 form
+            tgt.estimate_normals(15, compat=n_target <= 2_000_000, want=False)
     else:
         tgt = _capi.Target.voxels(ctx, target, voxel_size, 10)
     sc = _capi.Scan(ctx, scan)

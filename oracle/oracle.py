@@ -192,10 +192,11 @@ def eigh3(A):
 
 
 def normals_from_knn(points, knn_idx, compat=True):
+    """One normal per ROW of knn_idx (indices into points): rows may be a subset of the cloud."""
     p = _c(points, np.float32)
     idx = _c(knn_idx, np.int64)
-    out = np.empty_like(p)
-    lib().orc_normals_from_knn(p, p.shape[0], idx, idx.shape[1], int(bool(compat)), out)
+    out = np.empty((idx.shape[0], 3), np.float32)
+    lib().orc_normals_from_knn(p, idx.shape[0], idx, idx.shape[1], int(bool(compat)), out)
     return out
 
 

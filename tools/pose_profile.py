@@ -34,7 +34,7 @@ print(f"[{a.config}] data {time.time() - t0:.1f}s", flush=True)
 if kind_name in ("icp", "plane"):
     tgt = _capi.Target.points(ctx, target)
     if kind_name == "plane":
-        tgt.estimate_normals(15, compat=True, want=False)
+        tgt.estimate_normals(15, compat=n_target <= 2_000_000, want=False)
 else:
     tgt = _capi.Target.voxels(ctx, target, voxel_size, 10)
 sc = _capi.Scan(ctx, scan)
