@@ -370,10 +370,10 @@ __global__ void __launch_bounds__(256) k_linearize(const LinArgs a) {
 #define PCR_TILE_STATIC_ROUNDS 1   // 2 static rounds already unbalance the far poses (whole kernel 127 -> 155 us)
 #endif
 #define PCR_TILE_SUB (PCR_TILE_CTRS / 8)
-template <int VOXEL, int SEED>
-__global__ void __launch_bounds__(256) k_nn_scan(const LinArgs a) {
-    PoseK P;
-    if (!load_pose<false>(a, P)) return;
+// calls body(first, end) wave-uniformly for every 64-point tile this wave is given: lane l owns scan
+// point first + l, which exists iff first + l < end
+template <typename Body>
+__device__ __forceinline__ void nn_tile_loop(const LinArgs &a, Body &&body) {
     const int xcd = (int)(blockIdx.x & 7);
     const int lane = threadIdx.x & 63;
     const int64_t span = (((a.n + PCR_TILE_CTRS - 1) / PCR_TILE_CTRS) + 63) & ~(int64_t)63;
@@ -383,13 +383,12 @@ __global__ void __launch_bounds__(256) k_nn_scan(const LinArgs a) {
     const uint32_t wrank = (xb / PCR_TILE_SUB) * 4 + (threadIdx.x >> 6);
     const uint32_t wcount = ((nxb - home + PCR_TILE_SUB - 1) / PCR_TILE_SUB) * 4;
 #if PCR_NN_STATIC
-    const int sub = home;
-    const int c = xcd + 8 * sub;
-    const int64_t lo = span * c;
-    const int64_t end = lo + span < a.n ? lo + span : a.n;
-    uint32_t t = wrank;
-    for (;; t += wcount) {
-        {
+    {
+        const int c = xcd + 8 * home;
+        const int64_t lo = span * c;
+        const int64_t end = lo + span < a.n ? lo + span : a.n;
+        for (uint32_t t = wrank; lo + (int64_t)t * 64 < end; t += wcount) body(lo + (int64_t)t * 64, end);
+    }
 #else
     for (int r = 0; r < PCR_TILE_SUB; ++r) {
         const int sub = (home + r) % PCR_TILE_SUB;
@@ -412,38 +411,227 @@ __global__ void __launch_bounds__(256) k_nn_scan(const LinArgs a) {
                 if (lane == 0) t = atomicAdd(&a.tile_ctr[c * PCR_TILE_STRIDE], 1u);
                 t = __builtin_amdgcn_readfirstlane(t) + nstatic;
             }
-#endif
-        const int64_t i = lo + (int64_t)t * 64 + lane;
-        if (lo + (int64_t)t * 64 >= end) break;
-        if (i >= end) continue;
-        const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
-        uint32_t pj = PCR_NONE;
-        if (SEED) pj = a.nn_j[i];
-        float tx, ty, tz;
-        xform(P, x, y, z, tx, ty, tz);
-        uint32_t bj = PCR_NONE, bo = PCR_NONE;
-        bool ok;
-        if (!VOXEL) {
-            float best = a.bound2_f;
-#if PCR_NN_ABLATE == 1
-            bj = __float_as_uint(tx + ty + tz) & 0xffffu; best = 0.f;
-#elif PCR_NN_ABLATE == 2
-            { const NNCell<float> c = nn_cell<float>(a.gf, tx, ty, tz, a.bound2_f);
-              (void)nn_ring0<float, PtF>(a.gf, a.pts, a.cell_start, c, tx, ty, tz, best, bj, bo); }
-#else
-            if (SEED && pj != PCR_NONE) nn_test<float, PtF>(a.pts[pj], pj, tx, ty, tz, best, bj, bo);
-            nn_search<float, PtF, false, true>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
-#endif
-            ok = bj != PCR_NONE && __builtin_sqrtf(best) < a.md_f;
-        } else {
-            double best = a.bound2_d;
-            if (SEED && pj != PCR_NONE) nn_test<double, PtD>(a.means[pj], pj, (double)tx, (double)ty, (double)tz, best, bj, bo);
-            nn_search<double, PtD, false, true>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz, a.bound2_d, best, bj, bo);
-            ok = bj != PCR_NONE && __builtin_sqrt(best) < a.md_d;
-        }
-        a.nn_j[i] = ok ? bj : PCR_NONE;
+            if (lo + (int64_t)t * 64 >= end) break;
+            body(lo + (int64_t)t * 64, end);
         }
     }
+#endif
+}
+
+// one query per lane, every lane on its own (gathers): the general search
+template <int VOXEL, int SEED>
+__device__ __forceinline__ void nn_tile_perlane(const LinArgs &a, const PoseK &P, int64_t first, int64_t end) {
+    const int64_t i = first + (threadIdx.x & 63);
+    if (i >= end) return;
+    const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
+    uint32_t pj = PCR_NONE;
+    if (SEED) pj = a.nn_j[i];
+    float tx, ty, tz;
+    xform(P, x, y, z, tx, ty, tz);
+    uint32_t bj = PCR_NONE, bo = PCR_NONE;
+    bool ok;
+    if (!VOXEL) {
+        float best = a.bound2_f;
+#if PCR_NN_ABLATE == 1
+        bj = __float_as_uint(tx + ty + tz) & 0xffffu; best = 0.f;
+#elif PCR_NN_ABLATE == 2
+        { const NNCell<float> c = nn_cell<float>(a.gf, tx, ty, tz, a.bound2_f);
+          (void)nn_ring0<float, PtF>(a.gf, a.pts, a.cell_start, c, tx, ty, tz, best, bj, bo); }
+#else
+        if (SEED && pj != PCR_NONE) nn_test<float, PtF>(a.pts[pj], pj, tx, ty, tz, best, bj, bo);
+        nn_search<float, PtF, false, true>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
+#endif
+        ok = bj != PCR_NONE && __builtin_sqrtf(best) < a.md_f;
+    } else {
+        double best = a.bound2_d;
+        if (SEED && pj != PCR_NONE) nn_test<double, PtD>(a.means[pj], pj, (double)tx, (double)ty, (double)tz, best, bj, bo);
+        nn_search<double, PtD, false, true>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz, a.bound2_d, best, bj, bo);
+        ok = bj != PCR_NONE && __builtin_sqrt(best) < a.md_d;
+    }
+    a.nn_j[i] = ok ? bj : PCR_NONE;
+}
+
+template <int VOXEL, int SEED>
+__global__ void __launch_bounds__(256) k_nn_scan(const LinArgs a) {
+    PoseK P;
+    if (!load_pose<false>(a, P)) return;
+    nn_tile_loop(a, [&](int64_t first, int64_t end) { nn_tile_perlane<VOXEL, SEED>(a, P, first, end); });
+}
+
+// ---- wave-cooperative search (point targets) ---------------------------------------------------
+// The 64 queries of a tile are Morton neighbours moved by ONE rigid transform, so their search balls
+// overlap almost entirely.  Instead of 64 lanes gathering 64 different candidate lists (divergent
+// loops, one cache line per lane and load), the wave walks the rows of cells of the box spanned by all
+// its balls ONCE: every candidate is fetched with a wave-uniform address (one line, served to all
+// lanes) and tested by all 64 lanes; a row is skipped when no lane's bound reaches it.  No divergence,
+// no per-lane gathers.  The ball of a lane comes from an exact upper bound: its match of the previous
+// pass (seed) or, without one, whatever a first round over the lanes' own cells found.  Exactness: a
+// lane is certified when the ball of its final best lies inside a box whose needed rows were all
+// walked; anything else (box too large, too many candidates, still uncertified) goes to the per-lane
+// search, started from the best found so far.
+#ifndef PCR_COOP_CAP
+#define PCR_COOP_CAP 512        // staged points per wave (16 B each): 4 waves x 8 KB of LDS per block
+#endif
+#ifndef PCR_COOP_LDS
+#define PCR_COOP_LDS 1          // 1: candidates staged in LDS (async global->LDS copies); 0: uniform global loads
+#endif
+#if PCR_COOP_LDS
+#define PCR_COOP_MAX_CAND PCR_COOP_CAP
+#else
+#define PCR_COOP_MAX_CAND 1536
+#endif
+typedef __attribute__((address_space(1))) const void *gas_ptr;
+typedef __attribute__((address_space(3))) void *las_ptr;
+extern "C" __device__ int __ockl_wfred_min_i32(int);
+extern "C" __device__ int __ockl_wfred_max_i32(int);
+extern "C" __device__ unsigned __ockl_wfred_add_u32(unsigned);
+
+struct BallBox { int x0, x1, y0, y1, z0, z1; };
+
+// cells a ball of radius r around the query can reach, clamped to the grid (conservative: slack)
+__device__ __forceinline__ BallBox ball_cells(const Geom<float> &g, float tx, float ty, float tz, float r) {
+    BallBox b;
+    const float fx = (float)(g.nx - 1), fy = (float)(g.ny - 1), fz = (float)(g.nz - 1);
+    b.x0 = (int)fminf(fmaxf(floorf((tx - r - g.ox) * g.inv_h), 0.f), fx);
+    b.x1 = (int)fminf(fmaxf(floorf((tx + r - g.ox) * g.inv_h), 0.f), fx);
+    b.y0 = (int)fminf(fmaxf(floorf((ty - r - g.oy) * g.inv_h), 0.f), fy);
+    b.y1 = (int)fminf(fmaxf(floorf((ty + r - g.oy) * g.inv_h), 0.f), fy);
+    b.z0 = (int)fminf(fmaxf(floorf((tz - r - g.oz) * g.inv_h), 0.f), fz);
+    b.z1 = (int)fminf(fmaxf(floorf((tz + r - g.oz) * g.inv_h), 0.f), fz);
+    return b;
+}
+
+template <int SEED>
+__device__ __forceinline__ void nn_tile_coop(const LinArgs &a, const PoseK &P, PtF *stage, int64_t first, int64_t end) {
+    const Geom<float> &g = a.gf;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = first + lane;
+    const bool exists = i < end;
+    float x = 0.f, y = 0.f, z = 0.f;
+    uint32_t pj = PCR_NONE;
+    if (exists) {
+        x = a.sx[i]; y = a.sy[i]; z = a.sz[i];
+        if (SEED) pj = a.nn_j[i];
+    }
+    float tx, ty, tz;
+    xform(P, x, y, z, tx, ty, tz);
+    // NaN / inf queries match nothing (their distance never passes the gate)
+    const bool live = exists && fabsf(tx) <= 3.0e38f && fabsf(ty) <= 3.0e38f && fabsf(tz) <= 3.0e38f;
+    float best = a.bound2_f;
+    uint32_t bj = PCR_NONE, bo = PCR_NONE;
+    if (SEED && live && pj != PCR_NONE) nn_test<float, PtF>(a.pts[pj], pj, tx, ty, tz, best, bj, bo);
+    const NNCell<float> c = nn_cell<float>(g, tx, ty, tz, a.bound2_f);
+    const float rmax = __builtin_sqrtf(a.bound2_f) * 1.000002f + g.slack;
+    const uint32_t unx = (uint32_t)g.nx, uny = (uint32_t)g.ny;
+    bool pending = live;
+    for (int round = 0; round < 3; ++round) {
+        if (!__any(pending)) break;
+        // this round's box: union of the pending lanes' balls (round 0, nothing found yet: the own cell)
+        const bool has = best < a.bound2_f;
+        const float r = has ? RealTraits<float>::sqrt_fast(best) * 1.000002f + g.slack : (round == 0 ? 0.f : rmax);
+        const BallBox b = ball_cells(g, tx, ty, tz, r);
+        const int X0 = __ockl_wfred_min_i32(pending ? b.x0 : 0x7fffffff), X1 = __ockl_wfred_max_i32(pending ? b.x1 : -1);
+        const int Y0 = __ockl_wfred_min_i32(pending ? b.y0 : 0x7fffffff), Y1 = __ockl_wfred_max_i32(pending ? b.y1 : -1);
+        const int Z0 = __ockl_wfred_min_i32(pending ? b.z0 : 0x7fffffff), Z1 = __ockl_wfred_max_i32(pending ? b.z1 : -1);
+        const int by = Y1 - Y0 + 1, bz = Z1 - Z0 + 1, rows = by * bz;
+        bool coop = by > 0 && bz > 0 && rows <= 64;
+        uint32_t rs = 0, re = 0;
+        if (coop) {
+            if (lane < rows) {                                   // lane r fetches the point range of row r
+                const uint32_t ry = (uint32_t)(Y0 + lane % by), rz = (uint32_t)(Z0 + lane / by);
+                const uint32_t rowb = (rz * uny + ry) * unx;
+                rs = a.cell_start[rowb + (uint32_t)X0] & g.cs_mask;
+                re = a.cell_start[rowb + (uint32_t)X1 + 1u] & g.cs_mask;
+            }
+            coop = __ockl_wfred_add_u32(re - rs) <= PCR_COOP_MAX_CAND;
+        }
+        if (!coop) break;                                        // the per-lane search takes over below
+#if PCR_COOP_LDS
+        // ---- stage the rows of the box in LDS: asynchronous global->LDS copies, all in flight at once,
+        // ONE wait; the walk below then reads candidates as LDS broadcasts (~100 cycles instead of an L2
+        // round trip per batch)
+        {
+            uint32_t off = 0;
+            for (int r2 = 0; r2 < rows; ++r2) {
+                const uint32_t s_ = (uint32_t)__builtin_amdgcn_readlane((int)rs, r2);
+                const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)re, r2) - s_;
+                for (uint32_t o = 0; o < len; o += 64) {
+                    if (o + (uint32_t)lane < len)
+                        __builtin_amdgcn_global_load_lds((gas_ptr)(a.pts + s_ + o + lane), (las_ptr)(stage + off + o), 16, 0, 0);
+                }
+                off += len;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#endif
+        int rr = 0;
+        uint32_t roff = 0;                                       // LDS position of the current row's first point
+        for (int zz = Z0; zz <= Z1; ++zz) {
+            const int dzc = zz - c.cz;
+            float dzm = dzc == 0 ? 0.f : (dzc > 0 ? (float)dzc * g.h - c.fz : (float)(-dzc - 1) * g.h + c.fz);
+            dzm = fmaxf(dzm - g.slack, 0.f);
+            const float dz2 = dzm * dzm;
+            const bool zneed = __any(pending && dz2 <= best);
+            for (int yy = Y0; yy <= Y1; ++yy, ++rr) {
+                const uint32_t s_ = (uint32_t)__builtin_amdgcn_readlane((int)rs, rr);
+                const uint32_t e_ = (uint32_t)__builtin_amdgcn_readlane((int)re, rr);
+                const uint32_t base = roff;
+                roff += e_ - s_;
+                if (s_ == e_ || !zneed) continue;
+                const int dyc = yy - c.cy;
+                float dym = dyc == 0 ? 0.f : (dyc > 0 ? (float)dyc * g.h - c.fy : (float)(-dyc - 1) * g.h + c.fy);
+                dym = fmaxf(dym - g.slack, 0.f);
+                const float dyz2 = dz2 + dym * dym;
+                if (!__any(pending && dyz2 <= best)) continue;
+#if PCR_COOP_LDS
+                const PtF *q = stage + base;                     // wave-uniform LDS address: broadcast reads
+                uint32_t j = s_;
+                for (; j + 4 <= e_; j += 4, q += 4) {
+                    const PtF p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
+                    nn_test<float, PtF>(p0, j, tx, ty, tz, best, bj, bo);
+                    nn_test<float, PtF>(p1, j + 1, tx, ty, tz, best, bj, bo);
+                    nn_test<float, PtF>(p2, j + 2, tx, ty, tz, best, bj, bo);
+                    nn_test<float, PtF>(p3, j + 3, tx, ty, tz, best, bj, bo);
+                }
+                for (; j < e_; ++j, ++q) nn_test<float, PtF>(q[0], j, tx, ty, tz, best, bj, bo);
+#else
+                (void)base;
+                for (uint32_t j = s_; j < e_; j += 4) {          // wave-uniform addresses: one line for all lanes
+                    const PtF *__restrict__ q = a.pts + j;
+                    const PtF p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
+                    nn_test<float, PtF>(p0, j, tx, ty, tz, best, bj, bo);
+                    nn_test<float, PtF>(p1, j + 1, tx, ty, tz, best, bj, bo);
+                    nn_test<float, PtF>(p2, j + 2, tx, ty, tz, best, bj, bo);
+                    nn_test<float, PtF>(p3, j + 3, tx, ty, tz, best, bj, bo);
+                }
+#endif
+            }
+        }
+        // certified: the ball of what the lane holds now lies inside the box that was just walked
+        const bool has2 = best < a.bound2_f;
+        const float r2 = has2 ? RealTraits<float>::sqrt_fast(best) * 1.000002f + g.slack : rmax;
+        const BallBox b2 = ball_cells(g, tx, ty, tz, r2);
+        const bool inside = b2.x0 >= X0 && b2.x1 <= X1 && b2.y0 >= Y0 && b2.y1 <= Y1 && b2.z0 >= Z0 && b2.z1 <= Z1;
+        pending = pending && !inside;
+    }
+    if (pending) nn_search<float, PtF, false, true>(g, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
+    if (exists) {
+        const bool ok = live && bj != PCR_NONE && __builtin_sqrtf(best) < a.md_f;
+        a.nn_j[i] = ok ? bj : PCR_NONE;
+    }
+}
+
+template <int SEED>
+__global__ void __launch_bounds__(256) k_nn_coop(const LinArgs a) {
+    PoseK P;
+    if (!load_pose<false>(a, P)) return;
+#if PCR_COOP_LDS
+    __shared__ __attribute__((aligned(16))) PtF stage_all[4][PCR_COOP_CAP];
+    PtF *stage = stage_all[threadIdx.x >> 6];
+#else
+    PtF *stage = nullptr;
+#endif
+    nn_tile_loop(a, [&](int64_t first, int64_t end) { nn_tile_coop<SEED>(a, P, stage, first, end); });
 }
 
 // work counters of the search (instrumentation; same traversal as k_nn_scan<0>): out[0..3] = per-lane
@@ -786,10 +974,11 @@ pcr_status pcr_ensure_scratch(pcr_context *ctx, int64_t n_points) {
         const size_t ctr_words = 9 * 16 + (size_t)PCR_TILE_CTRS * PCR_TILE_STRIDE;
         HIP_TRY(hipMalloc(&ctx->d_tile_ctr, sizeof(uint32_t) * ctr_words));
         HIP_TRY(hipMemsetAsync(ctx->d_tile_ctr, 0, sizeof(uint32_t) * ctr_words, ctx->stream));
-        for (int v = 0; v < 2; ++v) {
+        for (int v = 0; v < 3; ++v) {
             int nb = 0;
             hipError_t e = v == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<0, 0>, 256, 0)
-                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<1, 0>, 256, 0);
+                         : v == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<1, 0>, 256, 0)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_coop<1>, 256, 0);
             ctx->nn_blocks_per_cu[v] = (e == hipSuccess && nb > 0) ? nb : 4;
         }
     }
@@ -862,7 +1051,7 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
     a.nblocks &= ~7;
     if (a.nblocks < 8) a.nblocks = 8;
     ps->fused_fin = ctx->variant == 1 && ctx->fuse_finalize;
-    ps->seed = ctx->variant == 1 && ctx->nn_mode == 1 && s->nn_serial == t->serial && s->nn_serial != 0;
+    ps->seed = ctx->variant == 1 && ctx->nn_mode >= 1 && s->nn_serial == t->serial && s->nn_serial != 0;
     FinArgs &f = ps->f;
     memset(&f, 0, sizeof f);
     f.partials = ctx->d_partials; f.tile_ctr = ctx->d_tile_ctr + 9 * 16; f.tickets = ctx->d_tile_ctr; f.nblocks = a.nblocks; f.kind = kind; f.out = ctx->d_out;
@@ -906,13 +1095,16 @@ static pcr_status pass_enqueue(Pass *ps) {
         pcr_prof_begin(ctx, PCR_K_NN, &ev);
         {   // exactly one resident generation of waves; they share the tiles dynamically
             const bool vox = ps->t->is_voxel != 0;
-            int64_t nb = (int64_t)ctx->num_cu * ctx->nn_blocks_per_cu[vox ? 1 : 0];
+            int64_t nb = (int64_t)ctx->num_cu * ctx->nn_blocks_per_cu[vox ? 1 : (ctx->nn_mode == 2 ? 2 : 0)];
             const int64_t need = ((a.n + 63) / 64 + 3) / 4;
             if (nb > need) nb = need;
             nb = (nb + 7) & ~(int64_t)7;
             if (nb < 8) nb = 8;
             const dim3 nn_grid((unsigned)nb);
-            if (!vox) {
+            if (!vox && ctx->nn_mode == 2) {
+                if (ps->seed) hipLaunchKernelGGL((k_nn_coop<1>), nn_grid, block, 0, ctx->stream, a);
+                else hipLaunchKernelGGL((k_nn_coop<0>), nn_grid, block, 0, ctx->stream, a);
+            } else if (!vox) {
                 if (ps->seed) hipLaunchKernelGGL((k_nn_scan<0, 1>), nn_grid, block, 0, ctx->stream, a);
                 else hipLaunchKernelGGL((k_nn_scan<0, 0>), nn_grid, block, 0, ctx->stream, a);
             } else {
@@ -920,7 +1112,7 @@ static pcr_status pass_enqueue(Pass *ps) {
                 else hipLaunchKernelGGL((k_nn_scan<1, 0>), nn_grid, block, 0, ctx->stream, a);
             }
             ps->s->nn_serial = ps->t->serial;      // nn_j now holds matches against this target
-            ps->seed = ctx->nn_mode == 1;          // ... which the next pass of a loop may start from
+            ps->seed = ctx->nn_mode >= 1;          // ... which the next pass of a loop may start from
         }
         pcr_prof_end(ctx, &ev);
         pcr_prof_begin(ctx, PCR_K_REDUCE, &ev);

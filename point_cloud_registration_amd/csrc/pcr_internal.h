@@ -129,11 +129,11 @@ struct pcr_context {
     double *d_trace = nullptr;
     int trace_cap = 0;
     int variant = 0;
-    int nn_mode = 0;             // 0 per-lane gathers; 1 seed the bound with the previous match; 2 LDS-staged
+    int nn_mode = 0;             // 0 per-lane search; 1 the same, seeded with the previous match; 2 wave-cooperative
     uint64_t next_serial = 1;    // targets get unique serial numbers (validity of a scan's previous matches)
     bool fuse_finalize = true;   // k_reduce_finalize (PCR_FUSE_FINALIZE=0: k_reduce + k_finalize)
     uint32_t *d_tile_ctr = nullptr;     // per-XCD dynamic tile counters of k_nn_scan
-    int nn_blocks_per_cu[2] = {4, 4};   // resident 256-thread blocks per CU of k_nn_scan<0/1>
+    int nn_blocks_per_cu[3] = {4, 4, 4};   // resident 256-thread blocks per CU of k_nn_scan<0/1>, k_nn_coop
     // profiling
     bool prof_on = false;
     int prof_period = 1;        // events around every prof_period-th pass (1 = every pass)

@@ -54,6 +54,7 @@ def rel_H(H, Href):
 PIPELINES = {
     "default": dict(variant=1, fuse_finalize=1, nn_mode=0),      # k_nn_scan + k_reduce_finalize
     "seeded": dict(variant=1, fuse_finalize=1, nn_mode=1),       # ... search seeded with the previous match
+    "coop": dict(variant=1, fuse_finalize=1, nn_mode=2),         # wave-cooperative search (k_nn_coop)
     "unfused": dict(variant=1, fuse_finalize=0, nn_mode=0),      # k_nn_scan + k_reduce + k_finalize
     "onekernel": dict(variant=0, fuse_finalize=1, nn_mode=0),    # k_linearize + k_finalize
 }

@@ -275,6 +275,7 @@ def test_profile_counters(capi, ctx, g2, pipeline):
     ctx.profile_enable(False)
     want = {"default": dict(nn=5, reduce=5, finalize=0, linearize=0),
             "seeded": dict(nn=5, reduce=5, finalize=0, linearize=0),
+            "coop": dict(nn=5, reduce=5, finalize=0, linearize=0),
             "unfused": dict(nn=5, reduce=5, finalize=5, linearize=0),
             "onekernel": dict(nn=0, reduce=0, finalize=5, linearize=5)}[pipeline]
     assert {k: prof[k][0] for k in want} == want
