@@ -269,7 +269,8 @@ def main():
                        "target_points": int(n_target), "scan_points_per_gpu": int(sc.n),
                        "max_dist": max_dist, "voxel_size": voxel_size, "parallelism": f"scan-shard x{world}",
                        "scan_points_job": int(n_scan_job),
-                       "nn_index": {"cell": info["cell"], "dims": info["dims"], "occupied_cells": info["occupied"]},
+                       "nn_index": {"cell": info["cell"], "dims": info["dims"], "occupied_cells": info["occupied"],
+                                    "halo_m": info["halo"], "halo_records": info["halo_records"]},
                        "gauss_newton_iters_to_converge": iters, "pose_error_m": round(pose_err, 6),
                        "correspondences_last_step": int(out[28]), "setup_s": round(t_setup, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",

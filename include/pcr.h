@@ -176,6 +176,10 @@ PCR_API pcr_status pcr_profile_reset(pcr_context *ctx);
 PCR_API pcr_status pcr_profile_read(pcr_context *ctx, int64_t launches[PCR_K_COUNT], double total_ms[PCR_K_COUNT]);
 /* grid geometry of a target's NN index: cell size, dims, occupied cells, points (or voxels) */
 PCR_API pcr_status pcr_target_index_info(pcr_target *t, double *cell, int64_t dims[3], int64_t *occupied, int64_t *n);
+/* point targets: margin (metres) and total records of the extended per-cell lists ring 0 searches (a cell's
+ * own points plus the neighbours' points within the margin of the shared face; PCR_HALO sets the margin as a
+ * fraction of the cell edge, default 0.1, 0 = none)                                                        */
+PCR_API pcr_status pcr_target_index_halo(pcr_target *t, double *halo, int64_t *records);
 /* work counters of the NN search for one pose (point targets): out[0..3] = rings entered, row
  * segments loaded, rows pruned by arithmetic, candidates tested, summed over queries; out[4..7] = the
  * same with each wave's maximum charged to all 64 lanes (the cost under divergence); out[8..10] =

@@ -37,7 +37,7 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = os.path.join(_HERE, "libpcr_oracle.so")
+    path = os.environ.get("PCR_ORACLE_LIB") or os.path.join(_HERE, "libpcr_oracle.so")   # (sanitizer build in tests)
     src = os.path.join(_HERE, "pcr_oracle.c")
     if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
         build()

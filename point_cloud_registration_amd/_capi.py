@@ -71,6 +71,7 @@ PROTOTYPES = {
     "pcr_profile_reset": (C.c_int, [_vp]),
     "pcr_profile_read": (C.c_int, [_vp, _i64p, _f64p]),
     "pcr_target_index_info": (C.c_int, [_vp, C.POINTER(C.c_double), _i64p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "pcr_target_index_halo": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pcr_set_variant": (C.c_int, [_vp, C.c_int]),
     "pcr_get_variant": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "pcr_set_nn_mode": (C.c_int, [_vp, C.c_int]),
@@ -381,7 +382,10 @@ class Target:
         cell, occ, n = C.c_double(0), C.c_int64(0), C.c_int64(0)
         dims = np.zeros(3, np.int64)
         check(lib().pcr_target_index_info(self.handle, C.byref(cell), dims, C.byref(occ), C.byref(n)))
-        return {"cell": cell.value, "dims": tuple(int(d) for d in dims), "occupied": occ.value, "n": n.value}
+        halo, nh = C.c_double(0), C.c_int64(0)
+        check(lib().pcr_target_index_halo(self.handle, C.byref(halo), C.byref(nh)))
+        return {"cell": cell.value, "dims": tuple(int(d) for d in dims), "occupied": occ.value, "n": n.value,
+                "halo": halo.value, "halo_records": nh.value}
 
     def nn_query(self, q, r_max=np.inf):
         q = np.ascontiguousarray(q, dtype=np.float32)

@@ -127,6 +127,34 @@ extern "C" pcr_status pcr_set_nn_mode(pcr_context *ctx, int mode) {
     return PCR_OK;
 }
 
+// ---- roctx ranges ------------------------------------------------------------------------------
+#include <dlfcn.h>
+static struct {
+    int state;                 // 0 unknown, 1 active, -1 off
+    int (*push)(const char *);
+    int (*pop)();
+} g_roctx;
+
+static bool roctx_on() {
+    if (g_roctx.state == 0) {
+        g_roctx.state = -1;
+        const char *e = getenv("PCR_ROCTX");
+        if (e && atoi(e) != 0) {
+            const char *names[] = {"libroctx64.so.4", "libroctx64.so", "/opt/rocm/lib/libroctx64.so"};
+            void *lib = nullptr;
+            for (const char *n : names) { lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+            if (lib) {
+                g_roctx.push = (int (*)(const char *))dlsym(lib, "roctxRangePushA");
+                g_roctx.pop = (int (*)())dlsym(lib, "roctxRangePop");
+                if (g_roctx.push && g_roctx.pop) g_roctx.state = 1;
+            }
+        }
+    }
+    return g_roctx.state == 1;
+}
+void pcr_roctx_push(const char *name) { if (roctx_on()) (void)g_roctx.push(name); }
+void pcr_roctx_pop() { if (roctx_on()) (void)g_roctx.pop(); }
+
 // ---- profiling: HIP events around every hot-path launch, on the launch stream ------------------
 void pcr_prof_begin(pcr_context *ctx, int kernel, ProfEvent *ev) {
     ev->kernel = -1;
@@ -201,7 +229,7 @@ static pcr_status upload(pcr_context *ctx, const T *host, size_t count, T **dev)
 
 static void target_free(pcr_target *t) {
     if (!t) return;
-    void *ptrs[] = {t->cell_start, t->cell_seed, t->pts, t->pn, t->means, t->vnorm, t->vicov,
+    void *ptrs[] = {t->cell_start, t->cell_seed, t->inv, t->cs_h, t->pts_h, t->pts, t->pn, t->means, t->vnorm, t->vicov,
                     t->st_mean, t->st_cov, t->st_norm, t->st_icov, t->st_counts, t->st_keys};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete t;
@@ -360,6 +388,13 @@ extern "C" pcr_status pcr_target_index_info(pcr_target *t, double *cell, int64_t
     }
     if (occupied) *occupied = t->occupied;
     if (n) *n = t->n;
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_target_index_halo(pcr_target *t, double *halo, int64_t *records) {
+    PCR_REQUIRE(t, "NULL argument");
+    if (halo) *halo = t->is_voxel ? 0.0 : (double)t->gf.halo;
+    if (records) *records = t->n_h;
     return PCR_OK;
 }
 

@@ -58,7 +58,8 @@ struct LinArgs {
     double *partials;  // [nblocks + 8][32]
     // variant 1: correspondences through HBM
     uint32_t *nn_j;
-    uint32_t *tile_ctr;   // 8 per-XCD tile counters (64 B apart) for k_nn_scan's dynamic scheduling
+    uint32_t *tile_ctr;   // tile counters (64 B apart) of the NN kernels' dynamic hand-out
+    int sched_local;      // 1: block-local hand-out (small scans), 0: global counters (see nn_tile_loop)
 };
 
 __device__ __forceinline__ float uniform_f32(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
@@ -323,16 +324,18 @@ __global__ void __launch_bounds__(256) k_linearize(const LinArgs a) {
         const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
         float tx, ty, tz;
         xform(P, x, y, z, tx, ty, tz);
-        uint32_t bj, bo;
+        uint32_t bj = PCR_NONE, bo;
         bool ok;
         if (KIND == PCR_ICP || KIND == PCR_PLANE) {
             float best;
-            nn_search<float, PtF>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
-            ok = bj != PCR_NONE && __builtin_sqrtf(best) < a.md_f;                 // icp.py:34 strict gate
+            nn_search<float, PtF>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bo);
+            ok = bo != PCR_NONE && __builtin_sqrtf(best) < a.md_f;                 // icp.py:34 strict gate
+            if (ok) bj = nn_sorted_index(a.gf, bo);
         } else {
             double best;
-            nn_search<double, PtD>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz, a.bound2_d, best, bj, bo);
-            ok = bj != PCR_NONE && __builtin_sqrt(best) < a.md_d;                 // voxelized_plane_icp.py:38
+            nn_search<double, PtD>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz, a.bound2_d, best, bo);
+            ok = bo != PCR_NONE && __builtin_sqrt(best) < a.md_d;                 // voxelized_plane_icp.py:38
+            if (ok) bj = nn_sorted_index(a.gd, bo);
         }
         if (ok) accumulate<KIND>(acc, a, P, bj, x, y, z, tx, ty, tz);
     }
@@ -372,50 +375,70 @@ __global__ void __launch_bounds__(256) k_linearize(const LinArgs a) {
 #define PCR_TILE_SUB (PCR_TILE_CTRS / 8)
 // calls body(first, end) wave-uniformly for every 64-point tile this wave is given: lane l owns scan
 // point first + l, which exists iff first + l < end
+// Two hand-out policies, chosen per launch (LinArgs::sched_local):
+//  * block-local (small scans: at most ~1.5 tiles per resident wave): the XCD's span is dealt round-robin
+//    to the XCD's blocks (block b owns tiles b, b + B, ...) and a block's four waves pull from that list
+//    through ONE counter in LDS -- no global atomics (they alone cost 24 us of a 1.06 M-point pass and
+//    ~10 us of a 100 k-point one).  Measured: 100 k-point scan 38.8 -> 30.6 us.
+//  * global counters (everything larger): PCR_TILE_CTRS sub-spans, one static round, then device-wide
+//    counters.  With many tiles per wave and costs that differ 10x between regions the static deal
+//    loses more than the atomics cost (1.06 M: 134 vs 147 us; 1e8-point target: 3.3 vs 4.9 ms).
 template <typename Body>
 __device__ __forceinline__ void nn_tile_loop(const LinArgs &a, Body &&body) {
     const int xcd = (int)(blockIdx.x & 7);
     const int lane = threadIdx.x & 63;
-    const int64_t span = (((a.n + PCR_TILE_CTRS - 1) / PCR_TILE_CTRS) + 63) & ~(int64_t)63;
-    // waves of this XCD that call sub-span `home` their home, and this wave's rank among them
     const uint32_t xb = blockIdx.x >> 3, nxb = gridDim.x >> 3;                 // block index / blocks on this XCD
+    __shared__ uint32_t blk_next;
+    if (a.sched_local) {
+        if (threadIdx.x == 0) blk_next = 0;
+        __syncthreads();
+    }
+    // global-counter state
+    const int64_t gspan = (((a.n + PCR_TILE_CTRS - 1) / PCR_TILE_CTRS) + 63) & ~(int64_t)63;
     const int home = (int)(xb % PCR_TILE_SUB);
     const uint32_t wrank = (xb / PCR_TILE_SUB) * 4 + (threadIdx.x >> 6);
     const uint32_t wcount = ((nxb - home + PCR_TILE_SUB - 1) / PCR_TILE_SUB) * 4;
-#if PCR_NN_STATIC
-    {
-        const int c = xcd + 8 * home;
-        const int64_t lo = span * c;
-        const int64_t end = lo + span < a.n ? lo + span : a.n;
-        for (uint32_t t = wrank; lo + (int64_t)t * 64 < end; t += wcount) body(lo + (int64_t)t * 64, end);
-    }
-#else
-    for (int r = 0; r < PCR_TILE_SUB; ++r) {
-        const int sub = (home + r) % PCR_TILE_SUB;
-        const int c = xcd + 8 * sub;
-        const int64_t lo = span * c;
-        const int64_t end = lo + span < a.n ? lo + span : a.n;
-        // static tiles of sub-span `sub`: PCR_TILE_STATIC_ROUNDS per home wave of that sub-span
-        const uint32_t hcount = ((nxb - sub + PCR_TILE_SUB - 1) / PCR_TILE_SUB) * 4;
-        const uint32_t nstatic = PCR_TILE_STATIC_ROUNDS * hcount;
-        int sr = r == 0 ? 0 : PCR_TILE_STATIC_ROUNDS;          // static rounds only at home
-        const uint32_t ntiles = end > lo ? (uint32_t)((end - lo + 63) >> 6) : 0u;
-        for (;;) {
-            uint32_t t = 0;
-            // every tile of this sub-span is a static one (small scans): no counter to ask
-            if (sr >= PCR_TILE_STATIC_ROUNDS && nstatic >= ntiles) break;
-            if (sr < PCR_TILE_STATIC_ROUNDS) {
-                t = wrank + (uint32_t)sr * wcount;
-                ++sr;
-            } else {
-                if (lane == 0) t = atomicAdd(&a.tile_ctr[c * PCR_TILE_STRIDE], 1u);
-                t = __builtin_amdgcn_readfirstlane(t) + nstatic;
+    int r = 0, sr = 0;
+    // block-local state
+    const int64_t lspan = (((a.n + 7) >> 3) + 63) & ~(int64_t)63;
+    for (;;) {
+        int64_t first, end;
+        if (a.sched_local) {
+            const int64_t lo = lspan * xcd;
+            end = lo + lspan < a.n ? lo + lspan : a.n;
+            uint32_t k = 0;
+            if (lane == 0) k = atomicAdd(&blk_next, 1u);               // ds_add_rtn_u32: no memory traffic
+            k = __builtin_amdgcn_readfirstlane(k);
+            first = lo + ((int64_t)xb + (int64_t)k * nxb) * 64;
+            if (first >= end) break;
+        } else {
+            bool got = false;
+            for (; r < PCR_TILE_SUB; ++r, sr = PCR_TILE_STATIC_ROUNDS) {     // static rounds only at home (r == 0)
+                const int sub = (home + r) % PCR_TILE_SUB;
+                const int c = xcd + 8 * sub;
+                const int64_t lo = gspan * c;
+                end = lo + gspan < a.n ? lo + gspan : a.n;
+                // static tiles of sub-span `sub`: PCR_TILE_STATIC_ROUNDS per home wave of that sub-span
+                const uint32_t hcount = ((nxb - sub + PCR_TILE_SUB - 1) / PCR_TILE_SUB) * 4;
+                const uint32_t nstatic = PCR_TILE_STATIC_ROUNDS * hcount;
+                const uint32_t ntiles = end > lo ? (uint32_t)((end - lo + 63) >> 6) : 0u;
+                uint32_t t;
+                if (sr < PCR_TILE_STATIC_ROUNDS) {
+                    t = wrank + (uint32_t)sr * wcount;
+                    ++sr;
+                } else {
+                    if (nstatic >= ntiles) continue;                   // every tile of this sub-span was a static one
+                    t = 0;
+                    if (lane == 0) t = atomicAdd(&a.tile_ctr[c * PCR_TILE_STRIDE], 1u);
+                    t = __builtin_amdgcn_readfirstlane(t) + nstatic;
+                }
+                first = lo + (int64_t)t * 64;
+                if (first < end) { got = true; break; }
             }
-            if (lo + (int64_t)t * 64 >= end) break;
-            body(lo + (int64_t)t * 64, end);
+            if (!got) break;
         }
+        body(first, end);
     }
-#endif
 }
 
 // one query per lane, every lane on its own (gathers): the general search
@@ -433,20 +456,22 @@ __device__ __forceinline__ void nn_tile_perlane(const LinArgs &a, const PoseK &P
     if (!VOXEL) {
         float best = a.bound2_f;
 #if PCR_NN_ABLATE == 1
-        bj = __float_as_uint(tx + ty + tz) & 0xffffu; best = 0.f;
+        bo = __float_as_uint(tx + ty + tz) & 0xffffu; best = 0.f;
 #elif PCR_NN_ABLATE == 2
-        { const NNCell<float> c = nn_cell<float>(a.gf, tx, ty, tz, a.bound2_f);
-          (void)nn_ring0<float, PtF>(a.gf, a.pts, a.cell_start, c, tx, ty, tz, best, bj, bo); }
+        { NNCell<float> c = nn_cell<float>(a.gf, tx, ty, tz, a.bound2_f);
+          (void)nn_ring0<float, PtF>(a.gf, a.pts, a.cell_start, c, tx, ty, tz, best, bo); }
 #else
-        if (SEED && pj != PCR_NONE) nn_test<float, PtF>(a.pts[pj], pj, tx, ty, tz, best, bj, bo);
-        nn_search<float, PtF, false, true>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
+        if (SEED && pj != PCR_NONE) nn_test<float, PtF>(a.pts[pj], tx, ty, tz, best, bo);
+        nn_search<float, PtF, false, true>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bo);
 #endif
-        ok = bj != PCR_NONE && __builtin_sqrtf(best) < a.md_f;
+        ok = bo != PCR_NONE && __builtin_sqrtf(best) < a.md_f;
+        if (ok) bj = nn_sorted_index(a.gf, bo);        // the winner's cell-sorted index: one 4-byte gather per query
     } else {
         double best = a.bound2_d;
-        if (SEED && pj != PCR_NONE) nn_test<double, PtD>(a.means[pj], pj, (double)tx, (double)ty, (double)tz, best, bj, bo);
-        nn_search<double, PtD, false, true>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz, a.bound2_d, best, bj, bo);
-        ok = bj != PCR_NONE && __builtin_sqrt(best) < a.md_d;
+        if (SEED && pj != PCR_NONE) nn_test<double, PtD>(a.means[pj], (double)tx, (double)ty, (double)tz, best, bo);
+        nn_search<double, PtD, false, true>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz, a.bound2_d, best, bo);
+        ok = bo != PCR_NONE && __builtin_sqrt(best) < a.md_d;
+        if (ok) bj = nn_sorted_index(a.gd, bo);
     }
     a.nn_j[i] = ok ? bj : PCR_NONE;
 }
@@ -518,8 +543,8 @@ __device__ __forceinline__ void nn_tile_coop(const LinArgs &a, const PoseK &P, P
     // NaN / inf queries match nothing (their distance never passes the gate)
     const bool live = exists && fabsf(tx) <= 3.0e38f && fabsf(ty) <= 3.0e38f && fabsf(tz) <= 3.0e38f;
     float best = a.bound2_f;
-    uint32_t bj = PCR_NONE, bo = PCR_NONE;
-    if (SEED && live && pj != PCR_NONE) nn_test<float, PtF>(a.pts[pj], pj, tx, ty, tz, best, bj, bo);
+    uint32_t bo = PCR_NONE;
+    if (SEED && live && pj != PCR_NONE) nn_test<float, PtF>(a.pts[pj], tx, ty, tz, best, bo);
     const NNCell<float> c = nn_cell<float>(g, tx, ty, tz, a.bound2_f);
     const float rmax = __builtin_sqrtf(a.bound2_f) * 1.000002f + g.slack;
     const uint32_t unx = (uint32_t)g.nx, uny = (uint32_t)g.ny;
@@ -588,21 +613,21 @@ __device__ __forceinline__ void nn_tile_coop(const LinArgs &a, const PoseK &P, P
                 uint32_t j = s_;
                 for (; j + 4 <= e_; j += 4, q += 4) {
                     const PtF p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
-                    nn_test<float, PtF>(p0, j, tx, ty, tz, best, bj, bo);
-                    nn_test<float, PtF>(p1, j + 1, tx, ty, tz, best, bj, bo);
-                    nn_test<float, PtF>(p2, j + 2, tx, ty, tz, best, bj, bo);
-                    nn_test<float, PtF>(p3, j + 3, tx, ty, tz, best, bj, bo);
+                    nn_test<float, PtF>(p0, tx, ty, tz, best, bo);
+                    nn_test<float, PtF>(p1, tx, ty, tz, best, bo);
+                    nn_test<float, PtF>(p2, tx, ty, tz, best, bo);
+                    nn_test<float, PtF>(p3, tx, ty, tz, best, bo);
                 }
-                for (; j < e_; ++j, ++q) nn_test<float, PtF>(q[0], j, tx, ty, tz, best, bj, bo);
+                for (; j < e_; ++j, ++q) nn_test<float, PtF>(q[0], tx, ty, tz, best, bo);
 #else
                 (void)base;
                 for (uint32_t j = s_; j < e_; j += 4) {          // wave-uniform addresses: one line for all lanes
                     const PtF *__restrict__ q = a.pts + j;
                     const PtF p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
-                    nn_test<float, PtF>(p0, j, tx, ty, tz, best, bj, bo);
-                    nn_test<float, PtF>(p1, j + 1, tx, ty, tz, best, bj, bo);
-                    nn_test<float, PtF>(p2, j + 2, tx, ty, tz, best, bj, bo);
-                    nn_test<float, PtF>(p3, j + 3, tx, ty, tz, best, bj, bo);
+                    nn_test<float, PtF>(p0, tx, ty, tz, best, bo);
+                    nn_test<float, PtF>(p1, tx, ty, tz, best, bo);
+                    nn_test<float, PtF>(p2, tx, ty, tz, best, bo);
+                    nn_test<float, PtF>(p3, tx, ty, tz, best, bo);
                 }
 #endif
             }
@@ -614,10 +639,10 @@ __device__ __forceinline__ void nn_tile_coop(const LinArgs &a, const PoseK &P, P
         const bool inside = b2.x0 >= X0 && b2.x1 <= X1 && b2.y0 >= Y0 && b2.y1 <= Y1 && b2.z0 >= Z0 && b2.z1 <= Z1;
         pending = pending && !inside;
     }
-    if (pending) nn_search<float, PtF, false, true>(g, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
+    if (pending) nn_search<float, PtF, false, true>(g, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bo);
     if (exists) {
-        const bool ok = live && bj != PCR_NONE && __builtin_sqrtf(best) < a.md_f;
-        a.nn_j[i] = ok ? bj : PCR_NONE;
+        const bool ok = live && bo != PCR_NONE && __builtin_sqrtf(best) < a.md_f;
+        a.nn_j[i] = ok ? nn_sorted_index(g, bo) : PCR_NONE;
     }
 }
 
@@ -651,15 +676,15 @@ __global__ void __launch_bounds__(256) k_nn_counters(const LinArgs a, unsigned l
             const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
             xform(a.hp, x, y, z, tx, ty, tz);
         }
-        uint32_t bj = PCR_NONE, bo = PCR_NONE; float best = a.bound2_f;
+        uint32_t bo = PCR_NONE; float best = a.bound2_f;
         NNCell<float> c = nn_cell<float>(a.gf, tx, ty, tz, a.bound2_f);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         const unsigned long long t1 = __builtin_readcyclecounter();
         int kstart = 0;
-        if (live) kstart = nn_ring0<float, PtF, true>(a.gf, a.pts, a.cell_start, c, tx, ty, tz, best, bj, bo, &st);
+        if (live) kstart = nn_ring0<float, PtF, true>(a.gf, a.pts, a.cell_start, c, tx, ty, tz, best, bo, &st);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         const unsigned long long t2 = __builtin_readcyclecounter();
-        if (live) nn_rings<float, PtF, true>(a.gf, a.pts, a.cell_start, c, kstart, tx, ty, tz, best, bj, bo, &st);
+        if (live) nn_rings<float, PtF, true>(a.gf, a.pts, a.cell_start, c, kstart, tx, ty, tz, best, bo, &st);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         const unsigned long long t3 = __builtin_readcyclecounter();
         cyc[0] += t1 - t0; cyc[1] += t2 - t1; cyc[2] += t3 - t2;
@@ -947,8 +972,9 @@ __global__ void __launch_bounds__(256) k_nn_query(Geom<Real> g, const PT *pts, c
                                                   Real *dist, int64_t *idx) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= m) return;
-    Real best; uint32_t bj, bo;
-    nn_search<Real, PT>(g, pts, cs, (Real)q[3 * i], (Real)q[3 * i + 1], (Real)q[3 * i + 2], bound2, best, bj, bo);
+    Real best; uint32_t bo;
+    nn_search<Real, PT>(g, pts, cs, (Real)q[3 * i], (Real)q[3 * i + 1], (Real)q[3 * i + 2], bound2, best, bo);
+    uint32_t bj = bo;                              // (only tested against PCR_NONE below)
     Real d = RealTraits<Real>::sqrt_rn(best);
     if (bj != PCR_NONE && rmax < RealTraits<Real>::inf() && !(d < rmax)) bj = PCR_NONE;
     dist[i] = bj == PCR_NONE ? RealTraits<Real>::inf() : d;
@@ -1094,6 +1120,7 @@ static pcr_status pass_enqueue(Pass *ps) {
     } else {
         pcr_prof_begin(ctx, PCR_K_NN, &ev);
         {   // exactly one resident generation of waves; they share the tiles dynamically
+            RoctxRange range("pcr:nn_search");
             const bool vox = ps->t->is_voxel != 0;
             int64_t nb = (int64_t)ctx->num_cu * ctx->nn_blocks_per_cu[vox ? 1 : (ctx->nn_mode == 2 ? 2 : 0)];
             const int64_t need = ((a.n + 63) / 64 + 3) / 4;
@@ -1101,6 +1128,13 @@ static pcr_status pass_enqueue(Pass *ps) {
             nb = (nb + 7) & ~(int64_t)7;
             if (nb < 8) nb = 8;
             const dim3 nn_grid((unsigned)nb);
+            {   // hand-out policy: at most ~1.5 tiles per launched wave -> block-local (nn_tile_loop)
+                const int64_t tiles = (a.n + 63) / 64;
+                int local = tiles * 2 <= nb * 4 * 3 ? 1 : 0;
+                const char *e = getenv("PCR_TILE_LOCAL");
+                if (e && *e) local = atoi(e) != 0;
+                ps->a.sched_local = local;
+            }
             if (!vox && ctx->nn_mode == 2) {
                 if (ps->seed) hipLaunchKernelGGL((k_nn_coop<1>), nn_grid, block, 0, ctx->stream, a);
                 else hipLaunchKernelGGL((k_nn_coop<0>), nn_grid, block, 0, ctx->stream, a);
@@ -1116,6 +1150,7 @@ static pcr_status pass_enqueue(Pass *ps) {
         }
         pcr_prof_end(ctx, &ev);
         pcr_prof_begin(ctx, PCR_K_REDUCE, &ev);
+        RoctxRange range("pcr:reduce");
         switch (ps->kind) {
         case PCR_ICP: launch_reduce_kind<PCR_ICP>(ps, ps->fused_fin, grid); break;
         case PCR_PLANE: launch_reduce_kind<PCR_PLANE>(ps, ps->fused_fin, grid); break;
@@ -1168,6 +1203,7 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
     if (use_comm) {
         ProfEvent ev;
         pcr_prof_begin(ctx, PCR_K_ALLREDUCE, &ev);
+        RoctxRange range("pcr:allreduce29");
         pcr_status cs = pcr_comm_allreduce29(ctx, ctx->d_out);
         if (cs == PCR_OK && ctx->h_out_dev) {
             hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, ctx->d_out, ctx->h_out_dev,

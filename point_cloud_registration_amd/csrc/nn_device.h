@@ -49,30 +49,32 @@ __device__ __forceinline__ float dist2_f32(float dx, float dy, float dz) {
     return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
 
+// The search tracks (squared distance, ORIGINAL index) only; callers that need the cell-sorted index of
+// the winner (the reduce kernel's gather) look it up once per query in the target's inverse map
+// (Geom::inv) -- one select less per candidate test.
 template <typename Real, typename PT>
-__device__ __forceinline__ void nn_test(const PT &p, uint32_t j, Real qx, Real qy, Real qz,
-                                        Real &best, uint32_t &bj, uint32_t &borig) {
+__device__ __forceinline__ void nn_test(const PT &p, Real qx, Real qy, Real qz, Real &best, uint32_t &borig) {
     const Real dx = qx - (Real)p.x, dy = qy - (Real)p.y, dz = qz - (Real)p.z;
     const Real d = (dx * dx + dy * dy) + dz * dz;
     const uint32_t o = pt_orig(p);
     // straight-line selects (bitwise, not short-circuit): no exec-mask juggling in the hot loop
     const bool take = (d < best) | ((d == best) & (o < borig));
-    best = take ? d : best; bj = take ? j : bj; borig = take ? o : borig;
+    best = take ? d : best; borig = take ? o : borig;
 }
 
 // float32 specialisation: d >= 0, so the bit patterns of squared distances order like the values and
 // (distance, original index) packs into ONE unsigned 64-bit key -- "closer, ties to the smaller
 // index" becomes a single 64-bit compare instead of three compares and two mask operations.
 template <>
-__device__ __forceinline__ void nn_test<float, float4>(const float4 &p, uint32_t j, float qx, float qy, float qz,
-                                                       float &best, uint32_t &bj, uint32_t &borig) {
+__device__ __forceinline__ void nn_test<float, float4>(const float4 &p, float qx, float qy, float qz,
+                                                       float &best, uint32_t &borig) {
     const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
     const float d = dist2_f32(dx, dy, dz);
     const uint32_t o = pt_orig(p);
     const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | o;
     const unsigned long long cur = ((unsigned long long)__float_as_uint(best) << 32) | borig;
     const bool take = key < cur;
-    best = take ? d : best; bj = take ? j : bj; borig = take ? o : borig;
+    best = take ? d : best; borig = take ? o : borig;
 }
 
 // The search is latency-bound (one L2 round trip per dependent load, ~500 cycles): candidates are
@@ -86,15 +88,14 @@ __device__ __forceinline__ void nn_test<float, float4>(const float4 &p, uint32_t
 #endif
 template <typename Real, typename PT>
 __device__ __forceinline__ void nn_scan_range(const PT *__restrict__ pts, uint32_t s, uint32_t e,
-                                              Real qx, Real qy, Real qz,
-                                              Real &best, uint32_t &bj, uint32_t &borig) {
+                                              Real qx, Real qy, Real qz, Real &best, uint32_t &borig) {
     for (uint32_t j = s; j < e; j += PCR_NN_BATCH) {
         const PT *__restrict__ b = pts + j;
         PT p[PCR_NN_BATCH];
 #pragma unroll
         for (int u = 0; u < PCR_NN_BATCH; ++u) p[u] = b[u];
 #pragma unroll
-        for (int u = 0; u < PCR_NN_BATCH; ++u) nn_test<Real, PT>(p[u], j + u, qx, qy, qz, best, bj, borig);
+        for (int u = 0; u < PCR_NN_BATCH; ++u) nn_test<Real, PT>(p[u], qx, qy, qz, best, borig);
     }
 }
 
@@ -109,6 +110,8 @@ struct NNCell {
     Real fx, fy, fz;       // offsets of the query inside that cell, in [0, h)
     Real fmin_;            // distance to the nearest face of that cell
     int k0, kmax;          // first ring that can touch the grid box / last ring worth visiting
+    Real reach0;           // ring 0 looked at everything within fmin_ + reach0 (the halo margin when the
+                           // cell's extended list was scanned, else 0)
 };
 
 template <typename Real>
@@ -121,6 +124,7 @@ __device__ __forceinline__ NNCell<Real> nn_cell(const Geom<Real> &g, Real qx, Re
     c.cx = (int)RT::floor_(rx); c.cy = (int)RT::floor_(ry); c.cz = (int)RT::floor_(rz);
     c.fx = (qx - g.ox) - (Real)c.cx * g.h; c.fy = (qy - g.oy) - (Real)c.cy * g.h; c.fz = (qz - g.oz) - (Real)c.cz * g.h;
     c.fmin_ = fmin(fmin(fmin(c.fx, g.h - c.fx), fmin(c.fy, g.h - c.fy)), fmin(c.fz, g.h - c.fz));
+    c.reach0 = (Real)0;
     c.k0 = max(max(max(-c.cx, c.cx - (g.nx - 1)), max(-c.cy, c.cy - (g.ny - 1))), max(max(-c.cz, c.cz - (g.nz - 1)), 0));
     c.kmax = max(max(max(c.cx, g.nx - 1 - c.cx), max(c.cy, g.ny - 1 - c.cy)), max(c.cz, g.nz - 1 - c.cz));
     if (bound2 < RT::inf()) {
@@ -132,23 +136,32 @@ __device__ __forceinline__ NNCell<Real> nn_cell(const Geom<Real> &g, Real qx, Re
 
 // Ring 0 (the query's own cell) and the empty-space shortcut, from ONE pair of loads (the cell's
 // range and its gap field).  Returns the first ring that still has to be visited (>= 1).
+// With a halo (point targets): the cell's EXTENDED list is scanned instead -- its own points plus
+// every point of the 26 neighbours that lies within `halo` of the shared face / edge / corner.  Any
+// point that is not on that list is farther than fmin_ + halo from a query inside the cell, so a
+// nearly converged query (residual << halo) is certified by ring 0 alone and never enters the ring
+// loop: without the halo the ~8 % of lanes that sit closer to a face than to their match drag their
+// whole wave through ring 1 (measured: 75 % of the wave time at the converged pose).
 template <typename Real, typename PT, bool STATS = false>
 __device__ __forceinline__ int nn_ring0(const Geom<Real> &g, const PT *__restrict__ pts, const uint32_t *__restrict__ cs,
-                                        const NNCell<Real> &c, Real qx, Real qy, Real qz,
-                                        Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr) {
+                                        NNCell<Real> &c, Real qx, Real qy, Real qz,
+                                        Real &best, uint32_t &borig, NNStats *st = nullptr) {
     if (c.k0 != 0) return c.k0;                   // outside the grid box: rings below k0 hold no cells
     const uint32_t own = ((uint32_t)c.cz * (uint32_t)g.ny + (uint32_t)c.cy) * (uint32_t)g.nx + (uint32_t)c.cx;
-    const uint32_t w0 = cs[own], w1 = cs[own + 1];
+    const bool ext = g.cs_h != nullptr;
+    const uint32_t *__restrict__ csr = ext ? g.cs_h : cs;
+    const uint32_t w0 = csr[own], w1 = csr[own + 1];
     const int gap = g.cs_mask != 0xffffffffu ? (int)(w0 >> PCR_GAP_SHIFT) : 0;
     if (gap == 0) {
         const uint32_t s_ = w0 & g.cs_mask, e_ = w1 & g.cs_mask;
         if (STATS) { st->rings++; st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-        nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
+        nn_scan_range<Real, PT>(ext ? (const PT *)g.pts_h : pts, s_, e_, qx, qy, qz, best, borig);
+        if (ext) c.reach0 = g.halo;
         return 1;
     }
     if (g.seed) {                                 // a real point nearby bounds the search from the start
         const uint32_t j0 = g.seed[own];
-        if (j0 != PCR_NONE) nn_test<Real, PT>(pts[j0], j0, qx, qy, qz, best, bj, borig);
+        if (j0 != PCR_NONE) nn_test<Real, PT>(pts[j0], qx, qy, qz, best, borig);
     }
     return gap;                                   // rings closer than `gap` are empty
 }
@@ -157,7 +170,7 @@ __device__ __forceinline__ int nn_ring0(const Geom<Real> &g, const PT *__restric
 template <typename Real>
 __device__ __forceinline__ bool nn_certified(const Geom<Real> &g, const NNCell<Real> &c, int k, Real best) {
     if (k > c.kmax) return true;
-    const Real lb = (Real)(k - 1) * g.h + c.fmin_ - g.slack;
+    const Real lb = (Real)(k - 1) * g.h + c.fmin_ + (k == 1 ? c.reach0 : (Real)0) - g.slack;
     return lb > (Real)0 && lb * lb > best;
 }
 
@@ -165,7 +178,7 @@ __device__ __forceinline__ bool nn_certified(const Geom<Real> &g, const NNCell<R
 template <typename Real, typename PT, bool STATS = false>
 __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restrict__ pts, const uint32_t *__restrict__ cs,
                                          const NNCell<Real> &c, int kstart, Real qx, Real qy, Real qz,
-                                         Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr) {
+                                         Real &best, uint32_t &borig, NNStats *st = nullptr) {
     typedef RealTraits<Real> RT;
     const Real lim = (Real)1.0e9;
     const int cx = c.cx, cy = c.cy, cz = c.cz;
@@ -207,18 +220,18 @@ __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restri
                     if (xl <= xh) {
                         const uint32_t s_ = cs[row + (uint32_t)xl] & g.cs_mask, e_ = cs[row + (uint32_t)xh + 1u] & g.cs_mask;
                         if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-                        nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
+                        nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, borig);
                     }
                 } else {                                    // interior row of the ring: its two end cells
                     if (xa_in && dyz2 + dxa <= best) {
                         const uint32_t s_ = cs[row + (uint32_t)xa] & g.cs_mask, e_ = cs[row + (uint32_t)xa + 1u] & g.cs_mask;
                         if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-                        nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
+                        nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, borig);
                     }
                     if (xb_in && dyz2 + dxb <= best) {
                         const uint32_t s_ = cs[row + (uint32_t)xb] & g.cs_mask, e_ = cs[row + (uint32_t)xb + 1u] & g.cs_mask;
                         if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-                        nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
+                        nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, borig);
                     }
                 }
             }
@@ -226,17 +239,22 @@ __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restri
     }
 }
 
-// On return: bj = cell-sorted index of the nearest point (PCR_NONE if nothing closer than
-// sqrt(bound2)), best = its squared distance, borig = its original index.
-// SEEDED: best / bj / borig come in holding a real target point (any point is an exact upper bound:
-// the search then only has to look inside that radius) or (bound2, PCR_NONE, PCR_NONE).
+// On return: borig = ORIGINAL index of the nearest point (PCR_NONE if nothing closer than
+// sqrt(bound2)), best = its squared distance.  nn_sorted_index turns it into the cell-sorted index.
+// SEEDED: best / borig come in holding a real target point (any point is an exact upper bound:
+// the search then only has to look inside that radius) or (bound2, PCR_NONE).
 template <typename Real, typename PT, bool STATS = false, bool SEEDED = false>
 __device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restrict__ pts,
                                           const uint32_t *__restrict__ cs,
                                           Real qx, Real qy, Real qz, Real bound2,
-                                          Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr) {
-    if (!SEEDED) { best = bound2; bj = PCR_NONE; borig = PCR_NONE; }
-    const NNCell<Real> c = nn_cell<Real>(g, qx, qy, qz, bound2);
-    const int kstart = nn_ring0<Real, PT, STATS>(g, pts, cs, c, qx, qy, qz, best, bj, borig, st);
-    nn_rings<Real, PT, STATS>(g, pts, cs, c, kstart, qx, qy, qz, best, bj, borig, st);
+                                          Real &best, uint32_t &borig, NNStats *st = nullptr) {
+    if (!SEEDED) { best = bound2; borig = PCR_NONE; }
+    NNCell<Real> c = nn_cell<Real>(g, qx, qy, qz, bound2);
+    const int kstart = nn_ring0<Real, PT, STATS>(g, pts, cs, c, qx, qy, qz, best, borig, st);
+    nn_rings<Real, PT, STATS>(g, pts, cs, c, kstart, qx, qy, qz, best, borig, st);
+}
+
+template <typename Real>
+__device__ __forceinline__ uint32_t nn_sorted_index(const Geom<Real> &g, uint32_t borig) {
+    return borig == PCR_NONE ? PCR_NONE : g.inv[borig];
 }

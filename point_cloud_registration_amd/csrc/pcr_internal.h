@@ -47,6 +47,14 @@ struct Geom {
     // seed[c] (cells with gap > 0 only matter): index of a point in the nearest occupied cell; its
     // distance initialises the search bound of a query that lands in empty space
     const uint32_t *seed;
+    // inv[original index] = cell-sorted index (the search tracks original indices: the oracle's tie rule)
+    const uint32_t *inv;
+    // halo (point targets, 0 = none): cs_h / pts_h = per-cell EXTENDED lists, a cell's own points plus the
+    // points of its 26 neighbours within `halo` of the shared face / edge / corner; cs_h carries the same
+    // gap bits as cell_start.  Ring 0 scans the extended list and certifies everything within fmin + halo.
+    Real halo;
+    const uint32_t *cs_h;
+    const void *pts_h;
 };
 #define PCR_GAP_SHIFT 28
 #define PCR_GAP_MAX 15
@@ -155,6 +163,10 @@ struct pcr_target {
     int64_t occupied = 0;    // occupied cells of the NN grid
     uint32_t *cell_start = nullptr;
     uint32_t *cell_seed = nullptr;
+    uint32_t *inv = nullptr;         // original -> cell-sorted index
+    uint32_t *cs_h = nullptr;        // extended (halo) lists of point targets
+    PtF *pts_h = nullptr;
+    int64_t n_h = 0;                 // records in pts_h
     // point targets
     Geom<float> gf;
     PtF *pts = nullptr;        // cell-sorted (the NN search reads these 16-byte records)
@@ -198,6 +210,15 @@ pcr_status pcr_run_align(pcr_target *t, pcr_scan *s, int kind, const double T_in
                          double max_dist, unsigned flags, double T_out[16], int *iterations, double *trace_or_null);
 pcr_status pcr_run_nn(pcr_target *t, const float *d_q, int64_t m, double r_max, void *d_dist, int64_t *d_idx, int f64);
 pcr_status pcr_ensure_scratch(pcr_context *ctx, int64_t n_points);
+
+// ---- roctx ranges around the hot-path launches (PCR_ROCTX=1; libroctx64 bound with dlopen, so the
+// library loads without it).  Shows up in rocprofv3 --marker-trace / the tool's timeline.
+void pcr_roctx_push(const char *name);
+void pcr_roctx_pop();
+struct RoctxRange {
+    explicit RoctxRange(const char *name) { pcr_roctx_push(name); }
+    ~RoctxRange() { pcr_roctx_pop(); }
+};
 
 // ---- profiling helpers (api.cpp)
 void pcr_prof_begin(pcr_context *ctx, int kernel, ProfEvent *ev);

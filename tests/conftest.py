@@ -43,6 +43,18 @@ def g6():
     return load_golden("g6_normals.npz")
 
 
+@pytest.fixture(scope="session")
+def g7():
+    """Full-scale normals fixture + the cloud it refers to (regenerated, checksum-guarded)."""
+    import zlib
+    from point_cloud_registration_amd.synthetic import street
+    g = load_golden("g7_normals_fullscale.npz")
+    pts = street(int(g["n"]), seed=0)
+    assert zlib.crc32(pts.tobytes()) == int(g["crc32"]), "street() no longer reproduces the cloud of the fixture"
+    g["points"] = pts
+    return g
+
+
 def rel_H(H, Href):
     """Parity metric of SURVEY.md section 8a Q5: max|dH| / max|H_ref|."""
     return float(np.max(np.abs(np.asarray(H) - np.asarray(Href))) / np.max(np.abs(Href)))

@@ -219,10 +219,33 @@ def g6():
     for k in (5, 15):
         n = ref.estimate_normals(pts, k=k)
         out[f"normals_k{k}"] = n
-    # the planar reference cloud, exaggerated scale, to expose the f32 single-pass covariance
     np.savez_compressed(os.path.join(HERE, "g6_normals.npz"), **out)
 
 
+def g7():
+    """Normals at FULL scale: the B-01 stand-in street(1_060_000, seed=0), |p| up to 67 m, real point
+    density, where the reference's float32 single-pass E[pp^T] - mu mu^T (estimate_normals.py:56-72)
+    cancels the most.  The cloud itself is regenerated by the tests from the same deterministic
+    generator (a checksum guards that); stored are the reference's normals of 20 000 sampled points,
+    the 2 000 farthest from the origin among them."""
+    import zlib
+    pts = street(1_060_000, seed=0)
+    rng = np.random.default_rng(11)
+    far = np.argsort(-np.linalg.norm(pts, axis=1))[:2000]
+    rest = rng.choice(pts.shape[0], 18000, replace=False)
+    sample = np.unique(np.concatenate([far, rest]))
+    out = {"sample": sample.astype(np.int64), "crc32": np.int64(zlib.crc32(pts.tobytes())),
+           "n": np.int64(pts.shape[0])}
+    for k in (5, 15):
+        n = ref.estimate_normals(pts, k=k)
+        out[f"normals_k{k}"] = np.ascontiguousarray(n[sample])
+    np.savez_compressed(os.path.join(HERE, "g7_normals_fullscale.npz"), **out)
+
+
 if __name__ == "__main__":
-    g1(); g2(); g3(); g5(); g6()
+    if len(sys.argv) > 1:
+        for name in sys.argv[1:]:
+            globals()[name]()
+    else:
+        g1(); g2(); g3(); g5(); g6(); g7()
     print("done")

@@ -167,3 +167,18 @@ def test_g6_normals(g6, k):
     dots = np.abs(np.sum(n * g6[f"normals_k{k}"], axis=1))
     # float32 covariance + float32 LAPACK eigh in the reference: compare where well conditioned
     assert np.mean(dots > 0.999) > 0.9
+
+
+@pytest.mark.parametrize("k", [5, 15])
+def test_g7_normals_full_scale(g7, k):
+    """The float32 single-pass covariance at B-01 scale (|p| up to 67 m, real density): the oracle's
+    compat normals are the reference's on (almost) every sampled point, far corners included."""
+    pts = g7["points"]
+    far = np.argsort(-np.linalg.norm(pts[g7["sample"]], axis=1))[:500]
+    pick = np.unique(np.concatenate([np.arange(1000), far]))
+    idx_pts = g7["sample"][pick]
+    _, idx = orc.knn_brute(pts, pts[idx_pts], k)
+    n = orc.normals_from_knn(pts, idx, compat=True)
+    dots = np.abs(np.sum(n.astype(np.float64) * g7[f"normals_k{k}"][pick], axis=1))
+    assert np.mean(dots > 0.999) >= 0.999, np.mean(dots > 0.999)
+    assert np.mean(dots > 1 - 1e-5) > 0.99
