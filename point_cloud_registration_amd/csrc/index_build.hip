@@ -205,59 +205,76 @@ __global__ void __launch_bounds__(256) k_gap_copy(const uint32_t *__restrict__ c
 }
 
 // ---- empty-space field: Chebyshev distance (in cells) to the nearest occupied cell -----------------
-__global__ void __launch_bounds__(256) k_gap_init(const uint32_t *__restrict__ cs, int64_t ncells, uint8_t *gap,
-                                                  uint32_t *seed) {
+// gap(c) = min over occupied cells o of max(|dx|, |dy|, |dz|), capped at PCR_GAP_MAX.  The L-infinity
+// distance separates: first the distance along x inside every row, then min over dy of max(that, |dy|),
+// then the same along z -- three passes of at most 31 reads per cell with an early exit (a candidate at
+// offset d cannot beat a value <= d), instead of 15 dilation passes over 27 neighbours each (65 ms for
+// the 251 M cells of the 1e8-point target).  Every pass carries the cell the minimum came from; its
+// first point becomes the seed of the empty cell.
+#define GAP_INF 255
+__global__ void __launch_bounds__(256) k_gap_x(const uint32_t *__restrict__ cs, int nx, int64_t ncells, uint8_t *gap,
+                                               uint32_t *src) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= ncells) return;
-    const bool occ = cs[c + 1] != cs[c];
-    gap[c] = occ ? 0 : 255;
-    seed[c] = occ ? cs[c] : 0xffffffffu;
+    const int x = (int)(c % nx);
+    uint8_t g = GAP_INF;
+    uint32_t from = 0xffffffffu;
+    for (int d = 0; d <= PCR_GAP_MAX; ++d) {
+        if (x - d >= 0 && cs[c - d + 1] != cs[c - d]) { g = (uint8_t)d; from = (uint32_t)(c - d); break; }
+        if (x + d < nx && cs[c + d + 1] != cs[c + d]) { g = (uint8_t)d; from = (uint32_t)(c + d); break; }
+    }
+    gap[c] = g; src[c] = from;
 }
 
-// one dilation step: an unreached cell with a neighbour (26-connectivity) at distance t-1 is at
-// distance t.  In place and race-free: only value-255 cells are written, only value t-1 is tested.
-__global__ void __launch_bounds__(256) k_gap_step(uint8_t *gap, uint32_t *seed, int nx, int ny, int nz, int t) {
+// along one more axis (stride = cells between neighbours on that axis, len = cells on it, pos = own index)
+__global__ void __launch_bounds__(256) k_gap_axis(const uint8_t *__restrict__ gin, const uint32_t *__restrict__ sin,
+                                                  int64_t ncells, int64_t stride, int len, int64_t period,
+                                                  uint8_t *gout, uint32_t *sout) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t ncells = (int64_t)nx * ny * nz;
-    if (c >= ncells || gap[c] != 255) return;
-    const int x = (int)(c % nx), y = (int)((c / nx) % ny), z = (int)(c / ((int64_t)nx * ny));
-    const uint8_t want = (uint8_t)(t - 1);
-    bool hit = false;
-    int64_t from = 0;
-    for (int dz = -1; dz <= 1 && !hit; ++dz) {
-        const int zz = z + dz;
-        if (zz < 0 || zz >= nz) continue;
-        for (int dy = -1; dy <= 1 && !hit; ++dy) {
-            const int yy = y + dy;
-            if (yy < 0 || yy >= ny) continue;
-            const int64_t row = ((int64_t)zz * ny + yy) * nx;
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int xx = x + dx;
-                if (xx >= 0 && xx < nx && gap[row + xx] == want) { hit = true; from = row + xx; break; }
-            }
+    if (c >= ncells) return;
+    const int pos = (int)((c % period) / stride);
+    int best = gin[c];
+    uint32_t from = sin[c];
+    for (int d = 1; d <= PCR_GAP_MAX && d < best; ++d) {          // a cell d away yields at least d
+        if (pos - d >= 0) {
+            const int v = max((int)gin[c - d * stride], d);
+            if (v < best) { best = v; from = sin[c - d * stride]; }
+        }
+        if (pos + d < len) {
+            const int v = max((int)gin[c + d * stride], d);
+            if (v < best) { best = v; from = sin[c + d * stride]; }
         }
     }
-    if (hit) { seed[c] = seed[from]; gap[c] = (uint8_t)t; }     // seed[from] was final one step ago
+    gout[c] = (uint8_t)best; sout[c] = from;
 }
 
-__global__ void __launch_bounds__(256) k_gap_pack(uint32_t *cs, int64_t ncells, const uint8_t *__restrict__ gap) {
+// gap bits into cell_start, source cell -> index of its first point (the seed)
+__global__ void __launch_bounds__(256) k_gap_pack(uint32_t *cs, int64_t ncells, const uint8_t *__restrict__ gap,
+                                                  const uint32_t *__restrict__ src, uint32_t *seed) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= ncells) return;
     const uint32_t g = gap[c] > PCR_GAP_MAX ? PCR_GAP_MAX : gap[c];
+    const uint32_t from = src[c];
+    // (cs of OTHER cells may already carry their gap bits: mask them off)
+    seed[c] = from == 0xffffffffu ? 0xffffffffu : (cs[from] & ((1u << PCR_GAP_SHIFT) - 1u));
     cs[c] |= g << PCR_GAP_SHIFT;
 }
 
 static pcr_status pack_gap_field(pcr_context *ctx, uint32_t *cs, int nx, int ny, int nz, uint32_t **seed_out) {
     const int64_t ncells = (int64_t)nx * ny * nz;
-    DevBuf<uint8_t> gap;
-    DevBuf<uint32_t> seed;
-    HIP_TRY(gap.alloc((size_t)ncells));
+    DevBuf<uint8_t> g1, g2;
+    DevBuf<uint32_t> s1, s2, seed;
+    HIP_TRY(g1.alloc((size_t)ncells)); HIP_TRY(g2.alloc((size_t)ncells));
+    HIP_TRY(s1.alloc((size_t)ncells)); HIP_TRY(s2.alloc((size_t)ncells));
     HIP_TRY(seed.alloc((size_t)ncells));
     const unsigned nb = (unsigned)((ncells + 255) / 256);
-    hipLaunchKernelGGL(k_gap_init, dim3(nb), dim3(256), 0, ctx->stream, cs, ncells, gap.p, seed.p);
-    for (int t = 1; t <= PCR_GAP_MAX; ++t)
-        hipLaunchKernelGGL(k_gap_step, dim3(nb), dim3(256), 0, ctx->stream, gap.p, seed.p, nx, ny, nz, t);
-    hipLaunchKernelGGL(k_gap_pack, dim3(nb), dim3(256), 0, ctx->stream, cs, ncells, (const uint8_t *)gap.p);
+    hipLaunchKernelGGL(k_gap_x, dim3(nb), dim3(256), 0, ctx->stream, (const uint32_t *)cs, nx, ncells, g1.p, s1.p);
+    hipLaunchKernelGGL(k_gap_axis, dim3(nb), dim3(256), 0, ctx->stream, (const uint8_t *)g1.p, (const uint32_t *)s1.p, ncells,
+                       (int64_t)nx, ny, (int64_t)nx * ny, g2.p, s2.p);
+    hipLaunchKernelGGL(k_gap_axis, dim3(nb), dim3(256), 0, ctx->stream, (const uint8_t *)g2.p, (const uint32_t *)s2.p, ncells,
+                       (int64_t)nx * ny, nz, ncells, g1.p, s1.p);
+    hipLaunchKernelGGL(k_gap_pack, dim3(nb), dim3(256), 0, ctx->stream, cs, ncells, (const uint8_t *)g1.p, (const uint32_t *)s1.p,
+                       seed.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     *seed_out = seed.release();

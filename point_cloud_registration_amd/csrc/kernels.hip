@@ -324,18 +324,16 @@ __global__ void __launch_bounds__(256) k_linearize(const LinArgs a) {
         const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
         float tx, ty, tz;
         xform(P, x, y, z, tx, ty, tz);
-        uint32_t bj = PCR_NONE, bo;
+        uint32_t bj, bo;
         bool ok;
         if (KIND == PCR_ICP || KIND == PCR_PLANE) {
             float best;
-            nn_search<float, PtF>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bo);
-            ok = bo != PCR_NONE && __builtin_sqrtf(best) < a.md_f;                 // icp.py:34 strict gate
-            if (ok) bj = nn_sorted_index(a.gf, bo);
+            nn_search<float, PtF>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
+            ok = bj != PCR_NONE && __builtin_sqrtf(best) < a.md_f;                 // icp.py:34 strict gate
         } else {
             double best;
-            nn_search<double, PtD>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz, a.bound2_d, best, bo);
-            ok = bo != PCR_NONE && __builtin_sqrt(best) < a.md_d;                 // voxelized_plane_icp.py:38
-            if (ok) bj = nn_sorted_index(a.gd, bo);
+            nn_search<double, PtD>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz, a.bound2_d, best, bj, bo);
+            ok = bj != PCR_NONE && __builtin_sqrt(best) < a.md_d;                 // voxelized_plane_icp.py:38
         }
         if (ok) accumulate<KIND>(acc, a, P, bj, x, y, z, tx, ty, tz);
     }
@@ -383,13 +381,13 @@ __global__ void __launch_bounds__(256) k_linearize(const LinArgs a) {
 //  * global counters (everything larger): PCR_TILE_CTRS sub-spans, one static round, then device-wide
 //    counters.  With many tiles per wave and costs that differ 10x between regions the static deal
 //    loses more than the atomics cost (1.06 M: 134 vs 147 us; 1e8-point target: 3.3 vs 4.9 ms).
-template <typename Body>
+template <int LOCAL, typename Body>
 __device__ __forceinline__ void nn_tile_loop(const LinArgs &a, Body &&body) {
     const int xcd = (int)(blockIdx.x & 7);
     const int lane = threadIdx.x & 63;
     const uint32_t xb = blockIdx.x >> 3, nxb = gridDim.x >> 3;                 // block index / blocks on this XCD
     __shared__ uint32_t blk_next;
-    if (a.sched_local) {
+    if (LOCAL) {
         if (threadIdx.x == 0) blk_next = 0;
         __syncthreads();
     }
@@ -403,7 +401,7 @@ __device__ __forceinline__ void nn_tile_loop(const LinArgs &a, Body &&body) {
     const int64_t lspan = (((a.n + 7) >> 3) + 63) & ~(int64_t)63;
     for (;;) {
         int64_t first, end;
-        if (a.sched_local) {
+        if (LOCAL) {
             const int64_t lo = lspan * xcd;
             end = lo + lspan < a.n ? lo + lspan : a.n;
             uint32_t k = 0;
@@ -441,8 +439,10 @@ __device__ __forceinline__ void nn_tile_loop(const LinArgs &a, Body &&body) {
     }
 }
 
-// one query per lane, every lane on its own (gathers): the general search
-template <int VOXEL, int SEED>
+// one query per lane, every lane on its own (gathers): the general search.  HALO: the target has the
+// extended per-cell lists (ring 0 reads those; the winner's cell-sorted index then comes from the inverse
+// map, one 4-byte gather per query); without them the search tracks the cell-sorted index itself.
+template <int VOXEL, int SEED, int HALO>
 __device__ __forceinline__ void nn_tile_perlane(const LinArgs &a, const PoseK &P, int64_t first, int64_t end) {
     const int64_t i = first + (threadIdx.x & 63);
     if (i >= end) return;
@@ -456,31 +456,47 @@ __device__ __forceinline__ void nn_tile_perlane(const LinArgs &a, const PoseK &P
     if (!VOXEL) {
         float best = a.bound2_f;
 #if PCR_NN_ABLATE == 1
-        bo = __float_as_uint(tx + ty + tz) & 0xffffu; best = 0.f;
+        bo = bj = __float_as_uint(tx + ty + tz) & 0xffffu; best = 0.f;
 #elif PCR_NN_ABLATE == 2
         { NNCell<float> c = nn_cell<float>(a.gf, tx, ty, tz, a.bound2_f);
-          (void)nn_ring0<float, PtF>(a.gf, a.pts, a.cell_start, c, tx, ty, tz, best, bo); }
+          (void)nn_ring0<float, PtF, false, HALO != 0>(a.gf, a.pts, a.cell_start, c, tx, ty, tz, best, bj, bo); }
 #else
-        if (SEED && pj != PCR_NONE) nn_test<float, PtF>(a.pts[pj], tx, ty, tz, best, bo);
-        nn_search<float, PtF, false, true>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bo);
+        if (SEED && pj != PCR_NONE) nn_test<float, PtF>(a.pts[pj], pj, tx, ty, tz, best, bj, bo);
+        nn_search<float, PtF, false, true, HALO != 0>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
 #endif
         ok = bo != PCR_NONE && __builtin_sqrtf(best) < a.md_f;
-        if (ok) bj = nn_sorted_index(a.gf, bo);        // the winner's cell-sorted index: one 4-byte gather per query
+        if (HALO && ok) bj = nn_sorted_index(a.gf, bo);
     } else {
         double best = a.bound2_d;
-        if (SEED && pj != PCR_NONE) nn_test<double, PtD>(a.means[pj], (double)tx, (double)ty, (double)tz, best, bo);
-        nn_search<double, PtD, false, true>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz, a.bound2_d, best, bo);
+        if (SEED && pj != PCR_NONE) nn_test<double, PtD>(a.means[pj], pj, (double)tx, (double)ty, (double)tz, best, bj, bo);
+        nn_search<double, PtD, false, true>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz, a.bound2_d, best, bj, bo);
         ok = bo != PCR_NONE && __builtin_sqrt(best) < a.md_d;
-        if (ok) bj = nn_sorted_index(a.gd, bo);
     }
     a.nn_j[i] = ok ? bj : PCR_NONE;
 }
 
-template <int VOXEL, int SEED>
-__global__ void __launch_bounds__(256) k_nn_scan(const LinArgs a) {
+// (5 waves per SIMD: the float64 centroid search sits at 101 VGPRs without the bound, which would cost it a
+// fifth of its occupancy and 10 % of its speed; the float32 search needs < 80 either way)
+template <int VOXEL, int SEED, int HALO, int LOCAL>
+__global__ void __launch_bounds__(256, 5) k_nn_scan(const LinArgs a) {
     PoseK P;
     if (!load_pose<false>(a, P)) return;
-    nn_tile_loop(a, [&](int64_t first, int64_t end) { nn_tile_perlane<VOXEL, SEED>(a, P, first, end); });
+    nn_tile_loop<LOCAL>(a, [&](int64_t first, int64_t end) { nn_tile_perlane<VOXEL, SEED, HALO>(a, P, first, end); });
+}
+
+// host-side choice of the instantiation
+template <int VOXEL>
+static void launch_nn_scan(bool seed, bool halo, bool local, dim3 grid, hipStream_t st, const LinArgs &a) {
+    const dim3 block(256);
+#define PCR_NN_CASE(S, H, L) hipLaunchKernelGGL((k_nn_scan<VOXEL, S, (VOXEL ? 0 : H), L>), grid, block, 0, st, a)
+    if (seed) {
+        if (halo) { if (local) PCR_NN_CASE(1, 1, 1); else PCR_NN_CASE(1, 1, 0); }
+        else { if (local) PCR_NN_CASE(1, 0, 1); else PCR_NN_CASE(1, 0, 0); }
+    } else {
+        if (halo) { if (local) PCR_NN_CASE(0, 1, 1); else PCR_NN_CASE(0, 1, 0); }
+        else { if (local) PCR_NN_CASE(0, 0, 1); else PCR_NN_CASE(0, 0, 0); }
+    }
+#undef PCR_NN_CASE
 }
 
 // ---- wave-cooperative search (point targets) ---------------------------------------------------
@@ -543,8 +559,8 @@ __device__ __forceinline__ void nn_tile_coop(const LinArgs &a, const PoseK &P, P
     // NaN / inf queries match nothing (their distance never passes the gate)
     const bool live = exists && fabsf(tx) <= 3.0e38f && fabsf(ty) <= 3.0e38f && fabsf(tz) <= 3.0e38f;
     float best = a.bound2_f;
-    uint32_t bo = PCR_NONE;
-    if (SEED && live && pj != PCR_NONE) nn_test<float, PtF>(a.pts[pj], tx, ty, tz, best, bo);
+    uint32_t bj = PCR_NONE, bo = PCR_NONE;
+    if (SEED && live && pj != PCR_NONE) nn_test<float, PtF>(a.pts[pj], pj, tx, ty, tz, best, bj, bo);
     const NNCell<float> c = nn_cell<float>(g, tx, ty, tz, a.bound2_f);
     const float rmax = __builtin_sqrtf(a.bound2_f) * 1.000002f + g.slack;
     const uint32_t unx = (uint32_t)g.nx, uny = (uint32_t)g.ny;
@@ -613,21 +629,21 @@ __device__ __forceinline__ void nn_tile_coop(const LinArgs &a, const PoseK &P, P
                 uint32_t j = s_;
                 for (; j + 4 <= e_; j += 4, q += 4) {
                     const PtF p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
-                    nn_test<float, PtF>(p0, tx, ty, tz, best, bo);
-                    nn_test<float, PtF>(p1, tx, ty, tz, best, bo);
-                    nn_test<float, PtF>(p2, tx, ty, tz, best, bo);
-                    nn_test<float, PtF>(p3, tx, ty, tz, best, bo);
+                    nn_test<float, PtF>(p0, j, tx, ty, tz, best, bj, bo);
+                    nn_test<float, PtF>(p1, j + 1, tx, ty, tz, best, bj, bo);
+                    nn_test<float, PtF>(p2, j + 2, tx, ty, tz, best, bj, bo);
+                    nn_test<float, PtF>(p3, j + 3, tx, ty, tz, best, bj, bo);
                 }
-                for (; j < e_; ++j, ++q) nn_test<float, PtF>(q[0], tx, ty, tz, best, bo);
+                for (; j < e_; ++j, ++q) nn_test<float, PtF>(q[0], j, tx, ty, tz, best, bj, bo);
 #else
                 (void)base;
                 for (uint32_t j = s_; j < e_; j += 4) {          // wave-uniform addresses: one line for all lanes
                     const PtF *__restrict__ q = a.pts + j;
                     const PtF p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
-                    nn_test<float, PtF>(p0, tx, ty, tz, best, bo);
-                    nn_test<float, PtF>(p1, tx, ty, tz, best, bo);
-                    nn_test<float, PtF>(p2, tx, ty, tz, best, bo);
-                    nn_test<float, PtF>(p3, tx, ty, tz, best, bo);
+                    nn_test<float, PtF>(p0, j, tx, ty, tz, best, bj, bo);
+                    nn_test<float, PtF>(p1, j + 1, tx, ty, tz, best, bj, bo);
+                    nn_test<float, PtF>(p2, j + 2, tx, ty, tz, best, bj, bo);
+                    nn_test<float, PtF>(p3, j + 3, tx, ty, tz, best, bj, bo);
                 }
 #endif
             }
@@ -639,10 +655,10 @@ __device__ __forceinline__ void nn_tile_coop(const LinArgs &a, const PoseK &P, P
         const bool inside = b2.x0 >= X0 && b2.x1 <= X1 && b2.y0 >= Y0 && b2.y1 <= Y1 && b2.z0 >= Z0 && b2.z1 <= Z1;
         pending = pending && !inside;
     }
-    if (pending) nn_search<float, PtF, false, true>(g, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bo);
+    if (pending) nn_search<float, PtF, false, true>(g, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
     if (exists) {
-        const bool ok = live && bo != PCR_NONE && __builtin_sqrtf(best) < a.md_f;
-        a.nn_j[i] = ok ? nn_sorted_index(g, bo) : PCR_NONE;
+        const bool ok = live && bj != PCR_NONE && __builtin_sqrtf(best) < a.md_f;
+        a.nn_j[i] = ok ? bj : PCR_NONE;
     }
 }
 
@@ -656,12 +672,14 @@ __global__ void __launch_bounds__(256) k_nn_coop(const LinArgs a) {
 #else
     PtF *stage = nullptr;
 #endif
-    nn_tile_loop(a, [&](int64_t first, int64_t end) { nn_tile_coop<SEED>(a, P, stage, first, end); });
+    if (a.sched_local) nn_tile_loop<1>(a, [&](int64_t first, int64_t end) { nn_tile_coop<SEED>(a, P, stage, first, end); });
+    else nn_tile_loop<0>(a, [&](int64_t first, int64_t end) { nn_tile_coop<SEED>(a, P, stage, first, end); });
 }
 
 // work counters of the search (instrumentation; same traversal as k_nn_scan<0>): out[0..3] = per-lane
 // sums of rings, rows loaded, rows pruned by arithmetic, candidates tested; out[4..7] = the same with
 // the per-WAVE maximum charged to all 64 lanes (what the SIMD actually executes under divergence)
+template <int HALO>
 __global__ void __launch_bounds__(256) k_nn_counters(const LinArgs a, unsigned long long *out) {
     const TileIter it(a);
     unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -676,15 +694,15 @@ __global__ void __launch_bounds__(256) k_nn_counters(const LinArgs a, unsigned l
             const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
             xform(a.hp, x, y, z, tx, ty, tz);
         }
-        uint32_t bo = PCR_NONE; float best = a.bound2_f;
+        uint32_t bj = PCR_NONE, bo = PCR_NONE; float best = a.bound2_f;
         NNCell<float> c = nn_cell<float>(a.gf, tx, ty, tz, a.bound2_f);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         const unsigned long long t1 = __builtin_readcyclecounter();
         int kstart = 0;
-        if (live) kstart = nn_ring0<float, PtF, true>(a.gf, a.pts, a.cell_start, c, tx, ty, tz, best, bo, &st);
+        if (live) kstart = nn_ring0<float, PtF, true, HALO != 0>(a.gf, a.pts, a.cell_start, c, tx, ty, tz, best, bj, bo, &st);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         const unsigned long long t2 = __builtin_readcyclecounter();
-        if (live) nn_rings<float, PtF, true>(a.gf, a.pts, a.cell_start, c, kstart, tx, ty, tz, best, bo, &st);
+        if (live) nn_rings<float, PtF, true>(a.gf, a.pts, a.cell_start, c, kstart, tx, ty, tz, best, bj, bo, &st);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         const unsigned long long t3 = __builtin_readcyclecounter();
         cyc[0] += t1 - t0; cyc[1] += t2 - t1; cyc[2] += t3 - t2;
@@ -966,15 +984,15 @@ __global__ void __launch_bounds__(64) k_publish(const double *__restrict__ out, 
 }
 
 // ---- fine seam: plain NN queries (no transform), original indices out -------------------------
-template <typename Real, typename PT>
+template <typename Real, typename PT, bool HALO>
 __global__ void __launch_bounds__(256) k_nn_query(Geom<Real> g, const PT *pts, const uint32_t *cs,
                                                   const float *q, int64_t m, Real bound2, Real rmax,
                                                   Real *dist, int64_t *idx) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= m) return;
-    Real best; uint32_t bo;
-    nn_search<Real, PT>(g, pts, cs, (Real)q[3 * i], (Real)q[3 * i + 1], (Real)q[3 * i + 2], bound2, best, bo);
-    uint32_t bj = bo;                              // (only tested against PCR_NONE below)
+    Real best; uint32_t bj, bo;
+    nn_search<Real, PT, false, false, HALO>(g, pts, cs, (Real)q[3 * i], (Real)q[3 * i + 1], (Real)q[3 * i + 2], bound2, best, bj, bo);
+    bj = bo;                                       // (only tested against PCR_NONE below)
     Real d = RealTraits<Real>::sqrt_rn(best);
     if (bj != PCR_NONE && rmax < RealTraits<Real>::inf() && !(d < rmax)) bj = PCR_NONE;
     dist[i] = bj == PCR_NONE ? RealTraits<Real>::inf() : d;
@@ -1002,8 +1020,8 @@ pcr_status pcr_ensure_scratch(pcr_context *ctx, int64_t n_points) {
         HIP_TRY(hipMemsetAsync(ctx->d_tile_ctr, 0, sizeof(uint32_t) * ctr_words, ctx->stream));
         for (int v = 0; v < 3; ++v) {
             int nb = 0;
-            hipError_t e = v == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<0, 0>, 256, 0)
-                         : v == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<1, 0>, 256, 0)
+            hipError_t e = v == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<0, 0, 1, 0>, 256, 0)
+                         : v == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<1, 0, 0, 0>, 256, 0)
                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_coop<1>, 256, 0);
             ctx->nn_blocks_per_cu[v] = (e == hipSuccess && nb > 0) ? nb : 4;
         }
@@ -1139,11 +1157,9 @@ static pcr_status pass_enqueue(Pass *ps) {
                 if (ps->seed) hipLaunchKernelGGL((k_nn_coop<1>), nn_grid, block, 0, ctx->stream, a);
                 else hipLaunchKernelGGL((k_nn_coop<0>), nn_grid, block, 0, ctx->stream, a);
             } else if (!vox) {
-                if (ps->seed) hipLaunchKernelGGL((k_nn_scan<0, 1>), nn_grid, block, 0, ctx->stream, a);
-                else hipLaunchKernelGGL((k_nn_scan<0, 0>), nn_grid, block, 0, ctx->stream, a);
+                launch_nn_scan<0>(ps->seed, ps->t->cs_h != nullptr, ps->a.sched_local != 0, nn_grid, ctx->stream, a);
             } else {
-                if (ps->seed) hipLaunchKernelGGL((k_nn_scan<1, 1>), nn_grid, block, 0, ctx->stream, a);
-                else hipLaunchKernelGGL((k_nn_scan<1, 0>), nn_grid, block, 0, ctx->stream, a);
+                launch_nn_scan<1>(ps->seed, false, ps->a.sched_local != 0, nn_grid, ctx->stream, a);
             }
             ps->s->nn_serial = ps->t->serial;      // nn_j now holds matches against this target
             ps->seed = ctx->nn_mode >= 1;          // ... which the next pass of a loop may start from
@@ -1333,13 +1349,17 @@ pcr_status pcr_run_nn(pcr_target *t, const float *d_q, int64_t m, double r_max, 
         const float inf = __builtin_inff();
         const double b = r_max * (1.0 + 1e-6);
         const float bound2 = bounded ? (float)(b * b) : inf;
-        hipLaunchKernelGGL((k_nn_query<float, PtF>), grid, block, 0, ctx->stream, t->gf, t->pts, t->cell_start, d_q, m,
-                           bound2, bounded ? (float)r_max : inf, (float *)d_dist, d_idx);
+        if (t->cs_h)
+            hipLaunchKernelGGL((k_nn_query<float, PtF, true>), grid, block, 0, ctx->stream, t->gf, t->pts, t->cell_start, d_q, m,
+                               bound2, bounded ? (float)r_max : inf, (float *)d_dist, d_idx);
+        else
+            hipLaunchKernelGGL((k_nn_query<float, PtF, false>), grid, block, 0, ctx->stream, t->gf, t->pts, t->cell_start, d_q, m,
+                               bound2, bounded ? (float)r_max : inf, (float *)d_dist, d_idx);
     } else {
         PCR_REQUIRE(t->is_voxel, "pcr_nn_query_f64 needs a voxel target");
         const double inf = __builtin_inf();
         const double b = r_max * (1.0 + 1e-6);
-        hipLaunchKernelGGL((k_nn_query<double, PtD>), grid, block, 0, ctx->stream, t->gd, t->means, t->cell_start, d_q, m,
+        hipLaunchKernelGGL((k_nn_query<double, PtD, false>), grid, block, 0, ctx->stream, t->gd, t->means, t->cell_start, d_q, m,
                            bounded ? b * b : inf, bounded ? r_max : inf, (double *)d_dist, d_idx);
     }
     pcr_prof_end(ctx, &ev);
@@ -1369,7 +1389,8 @@ extern "C" pcr_status pcr_nn_counters(pcr_target *t, pcr_scan *s, const double T
     DevBuf<unsigned long long> d;
     HIP_TRY(d.alloc(11));
     HIP_TRY(hipMemsetAsync(d.p, 0, sizeof h, ctx->stream));
-    hipLaunchKernelGGL(k_nn_counters, dim3(a.nblocks), dim3(256), 0, ctx->stream, a, d.p);
+    if (t->cs_h) hipLaunchKernelGGL(k_nn_counters<1>, dim3(a.nblocks), dim3(256), 0, ctx->stream, a, d.p);
+    else hipLaunchKernelGGL(k_nn_counters<0>, dim3(a.nblocks), dim3(256), 0, ctx->stream, a, d.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h, d.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));

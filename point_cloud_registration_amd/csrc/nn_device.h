@@ -49,32 +49,34 @@ __device__ __forceinline__ float dist2_f32(float dx, float dy, float dz) {
     return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
 
-// The search tracks (squared distance, ORIGINAL index) only; callers that need the cell-sorted index of
-// the winner (the reduce kernel's gather) look it up once per query in the target's inverse map
-// (Geom::inv) -- one select less per candidate test.
+// The search tracks (squared distance, original index) -- the oracle's tie rule -- and, for the reduce
+// kernel's gather, the index `j` of the winner in the array it was read from.  Where that index is not
+// wanted (halo searches: the extended lists hold copies, the cell-sorted index comes from Geom::inv
+// instead) the caller passes a dummy `bj` it never reads and the compiler drops that select.
 template <typename Real, typename PT>
-__device__ __forceinline__ void nn_test(const PT &p, Real qx, Real qy, Real qz, Real &best, uint32_t &borig) {
+__device__ __forceinline__ void nn_test(const PT &p, uint32_t j, Real qx, Real qy, Real qz,
+                                        Real &best, uint32_t &bj, uint32_t &borig) {
     const Real dx = qx - (Real)p.x, dy = qy - (Real)p.y, dz = qz - (Real)p.z;
     const Real d = (dx * dx + dy * dy) + dz * dz;
     const uint32_t o = pt_orig(p);
     // straight-line selects (bitwise, not short-circuit): no exec-mask juggling in the hot loop
     const bool take = (d < best) | ((d == best) & (o < borig));
-    best = take ? d : best; borig = take ? o : borig;
+    best = take ? d : best; bj = take ? j : bj; borig = take ? o : borig;
 }
 
 // float32 specialisation: d >= 0, so the bit patterns of squared distances order like the values and
 // (distance, original index) packs into ONE unsigned 64-bit key -- "closer, ties to the smaller
 // index" becomes a single 64-bit compare instead of three compares and two mask operations.
 template <>
-__device__ __forceinline__ void nn_test<float, float4>(const float4 &p, float qx, float qy, float qz,
-                                                       float &best, uint32_t &borig) {
+__device__ __forceinline__ void nn_test<float, float4>(const float4 &p, uint32_t j, float qx, float qy, float qz,
+                                                       float &best, uint32_t &bj, uint32_t &borig) {
     const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
     const float d = dist2_f32(dx, dy, dz);
     const uint32_t o = pt_orig(p);
     const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | o;
     const unsigned long long cur = ((unsigned long long)__float_as_uint(best) << 32) | borig;
     const bool take = key < cur;
-    best = take ? d : best; borig = take ? o : borig;
+    best = take ? d : best; bj = take ? j : bj; borig = take ? o : borig;
 }
 
 // The search is latency-bound (one L2 round trip per dependent load, ~500 cycles): candidates are
@@ -88,14 +90,14 @@ __device__ __forceinline__ void nn_test<float, float4>(const float4 &p, float qx
 #endif
 template <typename Real, typename PT>
 __device__ __forceinline__ void nn_scan_range(const PT *__restrict__ pts, uint32_t s, uint32_t e,
-                                              Real qx, Real qy, Real qz, Real &best, uint32_t &borig) {
+                                              Real qx, Real qy, Real qz, Real &best, uint32_t &bj, uint32_t &borig) {
     for (uint32_t j = s; j < e; j += PCR_NN_BATCH) {
         const PT *__restrict__ b = pts + j;
         PT p[PCR_NN_BATCH];
 #pragma unroll
         for (int u = 0; u < PCR_NN_BATCH; ++u) p[u] = b[u];
 #pragma unroll
-        for (int u = 0; u < PCR_NN_BATCH; ++u) nn_test<Real, PT>(p[u], qx, qy, qz, best, borig);
+        for (int u = 0; u < PCR_NN_BATCH; ++u) nn_test<Real, PT>(p[u], j + u, qx, qy, qz, best, bj, borig);
     }
 }
 
@@ -142,26 +144,26 @@ __device__ __forceinline__ NNCell<Real> nn_cell(const Geom<Real> &g, Real qx, Re
 // nearly converged query (residual << halo) is certified by ring 0 alone and never enters the ring
 // loop: without the halo the ~8 % of lanes that sit closer to a face than to their match drag their
 // whole wave through ring 1 (measured: 75 % of the wave time at the converged pose).
-template <typename Real, typename PT, bool STATS = false>
+template <typename Real, typename PT, bool STATS = false, bool HALO = false>
 __device__ __forceinline__ int nn_ring0(const Geom<Real> &g, const PT *__restrict__ pts, const uint32_t *__restrict__ cs,
                                         NNCell<Real> &c, Real qx, Real qy, Real qz,
-                                        Real &best, uint32_t &borig, NNStats *st = nullptr) {
+                                        Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr) {
     if (c.k0 != 0) return c.k0;                   // outside the grid box: rings below k0 hold no cells
     const uint32_t own = ((uint32_t)c.cz * (uint32_t)g.ny + (uint32_t)c.cy) * (uint32_t)g.nx + (uint32_t)c.cx;
-    const bool ext = g.cs_h != nullptr;
+    constexpr bool ext = HALO;                   // (HALO launches only happen for targets that have the lists)
     const uint32_t *__restrict__ csr = ext ? g.cs_h : cs;
     const uint32_t w0 = csr[own], w1 = csr[own + 1];
     const int gap = g.cs_mask != 0xffffffffu ? (int)(w0 >> PCR_GAP_SHIFT) : 0;
     if (gap == 0) {
         const uint32_t s_ = w0 & g.cs_mask, e_ = w1 & g.cs_mask;
         if (STATS) { st->rings++; st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-        nn_scan_range<Real, PT>(ext ? (const PT *)g.pts_h : pts, s_, e_, qx, qy, qz, best, borig);
+        nn_scan_range<Real, PT>(ext ? (const PT *)g.pts_h : pts, s_, e_, qx, qy, qz, best, bj, borig);
         if (ext) c.reach0 = g.halo;
         return 1;
     }
     if (g.seed) {                                 // a real point nearby bounds the search from the start
         const uint32_t j0 = g.seed[own];
-        if (j0 != PCR_NONE) nn_test<Real, PT>(pts[j0], qx, qy, qz, best, borig);
+        if (j0 != PCR_NONE) nn_test<Real, PT>(pts[j0], j0, qx, qy, qz, best, bj, borig);
     }
     return gap;                                   // rings closer than `gap` are empty
 }
@@ -178,7 +180,7 @@ __device__ __forceinline__ bool nn_certified(const Geom<Real> &g, const NNCell<R
 template <typename Real, typename PT, bool STATS = false>
 __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restrict__ pts, const uint32_t *__restrict__ cs,
                                          const NNCell<Real> &c, int kstart, Real qx, Real qy, Real qz,
-                                         Real &best, uint32_t &borig, NNStats *st = nullptr) {
+                                         Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr) {
     typedef RealTraits<Real> RT;
     const Real lim = (Real)1.0e9;
     const int cx = c.cx, cy = c.cy, cz = c.cz;
@@ -220,18 +222,18 @@ __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restri
                     if (xl <= xh) {
                         const uint32_t s_ = cs[row + (uint32_t)xl] & g.cs_mask, e_ = cs[row + (uint32_t)xh + 1u] & g.cs_mask;
                         if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-                        nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, borig);
+                        nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
                     }
                 } else {                                    // interior row of the ring: its two end cells
                     if (xa_in && dyz2 + dxa <= best) {
                         const uint32_t s_ = cs[row + (uint32_t)xa] & g.cs_mask, e_ = cs[row + (uint32_t)xa + 1u] & g.cs_mask;
                         if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-                        nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, borig);
+                        nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
                     }
                     if (xb_in && dyz2 + dxb <= best) {
                         const uint32_t s_ = cs[row + (uint32_t)xb] & g.cs_mask, e_ = cs[row + (uint32_t)xb + 1u] & g.cs_mask;
                         if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-                        nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, borig);
+                        nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
                     }
                 }
             }
@@ -240,18 +242,19 @@ __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restri
 }
 
 // On return: borig = ORIGINAL index of the nearest point (PCR_NONE if nothing closer than
-// sqrt(bound2)), best = its squared distance.  nn_sorted_index turns it into the cell-sorted index.
-// SEEDED: best / borig come in holding a real target point (any point is an exact upper bound:
-// the search then only has to look inside that radius) or (bound2, PCR_NONE).
-template <typename Real, typename PT, bool STATS = false, bool SEEDED = false>
+// sqrt(bound2)), best = its squared distance, bj = its cell-sorted index (HALO searches: undefined,
+// use nn_sorted_index).
+// SEEDED: best / bj / borig come in holding a real target point (any point is an exact upper bound:
+// the search then only has to look inside that radius) or (bound2, PCR_NONE, PCR_NONE).
+template <typename Real, typename PT, bool STATS = false, bool SEEDED = false, bool HALO = false>
 __device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restrict__ pts,
                                           const uint32_t *__restrict__ cs,
                                           Real qx, Real qy, Real qz, Real bound2,
-                                          Real &best, uint32_t &borig, NNStats *st = nullptr) {
-    if (!SEEDED) { best = bound2; borig = PCR_NONE; }
+                                          Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr) {
+    if (!SEEDED) { best = bound2; bj = PCR_NONE; borig = PCR_NONE; }
     NNCell<Real> c = nn_cell<Real>(g, qx, qy, qz, bound2);
-    const int kstart = nn_ring0<Real, PT, STATS>(g, pts, cs, c, qx, qy, qz, best, borig, st);
-    nn_rings<Real, PT, STATS>(g, pts, cs, c, kstart, qx, qy, qz, best, borig, st);
+    const int kstart = nn_ring0<Real, PT, STATS, HALO>(g, pts, cs, c, qx, qy, qz, best, bj, borig, st);
+    nn_rings<Real, PT, STATS>(g, pts, cs, c, kstart, qx, qy, qz, best, bj, borig, st);
 }
 
 template <typename Real>

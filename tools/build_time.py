@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from point_cloud_registration_amd import _capi
 from point_cloud_registration_amd.synthetic import street, street_tiled
 ctx = _capi.get_context(0)
-_capi.Target.points(ctx, street(10000)).close()
+w = street(20000)                      # warm-up: first use of every build kernel (code load) stays out of the timings
+_capi.Target.points(ctx, w).estimate_normals(15, want=False); _capi.Target.voxels(ctx, w, 1.0, 10).close(); _capi.Scan(ctx, w).close()
 for n in [int(float(a)) for a in (sys.argv[1:] or ["1.06e6", "1e7"])]:
     pts = street(n) if n <= 2_000_000 else street_tiled(n)
     t0 = time.perf_counter(); t = _capi.Target.points(ctx, pts); ctx.synchronize(); t1 = time.perf_counter()

@@ -15,6 +15,9 @@ except Exception as e:
     print("bench parse failed", sys.argv[1], e)
 PY
 done
+python tools/build_time.py 1.06e6 1e7 1e8 > $o/s_build_time.log 2>&1; tail -3 $o/s_build_time.log
+python tools/speed_test_comparison.py > $o/s_speed_test.log 2>&1; tail -8 $o/s_speed_test.log
+for c in plane_b01 icp_b01_harness plane_100m; do python tools/pose_profile.py --config $c --modes 0 --reps 10 > $o/s_pose_$c.log 2>&1; grep -h "mean\|walk\|align" $o/s_pose_$c.log; done
 tools/collect_profiles.sh r02_plane_b01 plane_b01
 tools/collect_profiles.sh r02_plane_b01_coop plane_b01 PCR_NN_MODE=2
 tools/collect_profiles.sh r02_plane_100m plane_100m
