@@ -12,21 +12,48 @@
 #endif
 
 // numpy.linalg.solve: LU with partial pivoting, exact-zero pivot = singular (quirk Q7).
-// A is caller-provided 6 x 7 working storage (shared memory on the device: dynamic row indices).
+// A is caller-provided 6 x 7 working storage.  Every loop has compile-time bounds and the row exchange is
+// written as a predicated swap against each candidate row, so that on the device the whole system stays in
+// registers (a run-time row index would send it through LDS / scratch: ~10 us for this one thread instead
+// of ~1); the arithmetic and its order are those of the textbook loop.
 PCR_HD static inline int gn_solve6(double (*A)[7], const double H[36], const double g[6], double x[6]) {
-    for (int i = 0; i < 6; ++i) { for (int j = 0; j < 6; ++j) A[i][j] = H[6 * i + j]; A[i][6] = g[i]; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) A[i][j] = H[6 * i + j];
+        A[i][6] = g[i];
+    }
+    int singular = 0;
+#pragma unroll
     for (int c = 0; c < 6; ++c) {
         int piv = c;
-        for (int r = c + 1; r < 6; ++r) if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
-        if (A[piv][c] == 0.0) return 1;
-        if (piv != c) for (int j = 0; j < 7; ++j) { const double tmp = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = tmp; }
+        double pmax = fabs(A[c][c]);
+#pragma unroll
+        for (int r = c + 1; r < 6; ++r) { const double v = fabs(A[r][c]); if (v > pmax) { pmax = v; piv = r; } }
+        if (pmax == 0.0) singular = 1;
+#pragma unroll
         for (int r = c + 1; r < 6; ++r) {
-            const double f = A[r][c] / A[c][c];
-            for (int j = c; j < 7; ++j) A[r][j] -= f * A[c][j];
+            const bool sw = piv == r;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const double a = A[c][j], b = A[r][j];
+                A[c][j] = sw ? b : a; A[r][j] = sw ? a : b;
+            }
+        }
+        if (!singular) {
+#pragma unroll
+            for (int r = c + 1; r < 6; ++r) {
+                const double f = A[r][c] / A[c][c];
+#pragma unroll
+                for (int j = c; j < 7; ++j) A[r][j] -= f * A[c][j];
+            }
         }
     }
+    if (singular) return 1;
+#pragma unroll
     for (int i = 5; i >= 0; --i) {
         double v = A[i][6];
+#pragma unroll
         for (int j = i + 1; j < 6; ++j) v -= A[i][j] * x[j];
         x[i] = v / A[i][i];
     }

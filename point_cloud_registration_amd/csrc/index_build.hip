@@ -139,22 +139,20 @@ __global__ void __launch_bounds__(256) k_count_occupied(const uint32_t *__restri
 }
 
 __global__ void __launch_bounds__(256) k_gather_f32(const float *__restrict__ xyz, const uint32_t *__restrict__ order,
-                                                    int64_t n, PtF *out, uint32_t *inv) {
+                                                    int64_t n, PtF *out) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     const uint32_t i = order[j];
     out[j] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], __uint_as_float(i));
-    inv[i] = (uint32_t)j;
 }
 
 __global__ void __launch_bounds__(256) k_gather_f64(const double *__restrict__ xyz, const uint32_t *__restrict__ order,
-                                                    int64_t n, PtD *out, uint32_t *inv) {
+                                                    int64_t n, PtD *out) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     const uint32_t i = order[j];
     out[j] = make_double4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2],
                           __longlong_as_double((long long)i));
-    inv[i] = (uint32_t)j;
 }
 
 // ---- halo: extended per-cell lists (point targets) ------------------------------------------------
@@ -191,11 +189,14 @@ __global__ void __launch_bounds__(256) k_halo_count(const PtF *__restrict__ pts,
 }
 
 __global__ void __launch_bounds__(256) k_halo_fill(const PtF *__restrict__ pts, int64_t n, Geom<float> g, uint32_t *cursor,
-                                                   PtF *out) {
+                                                   PtF *out, uint32_t *j_out) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     const PtF p = pts[j];
-    halo_cells(g, p.x, p.y, p.z, [&](uint32_t c) { out[atomicAdd(&cursor[c], 1u)] = p; });
+    halo_cells(g, p.x, p.y, p.z, [&](uint32_t c) {
+        const uint32_t e = atomicAdd(&cursor[c], 1u);
+        out[e] = p; j_out[e] = (uint32_t)j;
+    });
 }
 
 // cs_h gets the gap bits of the finished cell_start (same cells are empty in both)
@@ -298,7 +299,7 @@ static bool make_geom(const float lo[3], const float hi[3], double h, Geom<Real>
     g->slack = (Real)(16.0 * eps * (mag + h) + 1e-30);
     g->cs_mask = 0xffffffffu;
     g->seed = nullptr;
-    g->inv = nullptr; g->halo = (Real)0; g->cs_h = nullptr; g->pts_h = nullptr;
+    g->halo = (Real)0; g->cs_h = nullptr; g->pts_h = nullptr; g->j_h = nullptr;
     return true;
 }
 
@@ -338,9 +339,9 @@ static int bits_for(double ncells) {
 template <typename Real, typename T, typename PT>
 static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double h, bool auto_h, Geom<Real> *geom,
                              uint32_t **cell_start_out, uint32_t **seed_out, PT **pts_out, int64_t *occupied_out,
-                             uint32_t **inv_out, double halo_frac, uint32_t **cs_h_out, PtF **pts_h_out, int64_t *n_h_out) {
+                             double halo_frac, uint32_t **cs_h_out, PtF **pts_h_out, uint32_t **j_h_out, int64_t *n_h_out) {
     *seed_out = nullptr;
-    *cs_h_out = nullptr; *pts_h_out = nullptr; *n_h_out = 0;
+    *cs_h_out = nullptr; *pts_h_out = nullptr; *j_h_out = nullptr; *n_h_out = 0;
     PCR_REQUIRE(n < ((int64_t)1 << 31), "at most 2^31-1 points per target");
     HIP_TRY(hipSetDevice(ctx->device));
     float lo[3], hi[3];
@@ -409,8 +410,6 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
     HIP_TRY(d_cid.alloc(nn)); HIP_TRY(d_idx.alloc(nn));
     HIP_TRY(d_cid2.alloc(nn)); HIP_TRY(d_idx2.alloc(nn));
     DevBuf<PT> d_pts;
-    DevBuf<uint32_t> d_inv;
-    HIP_TRY(d_inv.alloc(nn));
     HIP_TRY(d_pts.alloc(nn + PCR_PTS_PAD));
     {   // sentinel records behind the last point (see nn_scan_range): +inf coordinates, index ~0
         PT pad[PCR_PTS_PAD];
@@ -428,10 +427,10 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
         PCR_TRY(sort_pairs<uint32_t>(ctx, d_cid, d_cid2, d_idx, d_idx2, n, bits_for(ncells)));
         if (sizeof(Real) == 4)
             hipLaunchKernelGGL(k_gather_f32, dim3(nb), dim3(256), 0, ctx->stream, (const float *)d_xyz,
-                               (const uint32_t *)d_idx2.p, n, (PtF *)d_pts.p, d_inv.p);
+                               (const uint32_t *)d_idx2.p, n, (PtF *)d_pts.p);
         else
             hipLaunchKernelGGL(k_gather_f64, dim3(nb), dim3(256), 0, ctx->stream, (const double *)d_xyz,
-                               (const uint32_t *)d_idx2.p, n, (PtD *)d_pts.p, d_inv.p);
+                               (const uint32_t *)d_idx2.p, n, (PtD *)d_pts.p);
     }
     PCR_TRY(exclusive_scan_u32(ctx, d_counts, (int64_t)ncells + 1));
     if (n > 0 && n < ((int64_t)1 << PCR_GAP_SHIFT)) {
@@ -451,9 +450,8 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
         occupied = (int64_t)nz2;
     }
     // ---- halo lists (point targets with a gap field: both share the 28-bit offsets)
-    g.inv = d_inv.p;
-    g.halo = (Real)0; g.cs_h = nullptr; g.pts_h = nullptr;
-    DevBuf<uint32_t> d_cs_h;
+    g.halo = (Real)0; g.cs_h = nullptr; g.pts_h = nullptr; g.j_h = nullptr;
+    DevBuf<uint32_t> d_cs_h, d_j_h;
     DevBuf<PtF> d_pts_h;
     int64_t n_h = 0;
     if (sizeof(Real) == 4 && halo_frac > 0 && n > 0 && g.cs_mask != 0xffffffffu) {
@@ -475,6 +473,7 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
             HIP_TRY(cursor.alloc(nc1));
             HIP_TRY(hipMemcpyAsync(cursor.p, d_cs_h.p, sizeof(uint32_t) * nc1, hipMemcpyDeviceToDevice, ctx->stream));
             HIP_TRY(d_pts_h.alloc((size_t)n_h + PCR_PTS_PAD));
+            HIP_TRY(d_j_h.alloc((size_t)n_h + PCR_PTS_PAD));
             {
                 PtF pad[PCR_PTS_PAD];
                 for (int i = 0; i < PCR_PTS_PAD; ++i) {
@@ -483,12 +482,12 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
                 }
                 HIP_TRY(hipMemcpyAsync(d_pts_h.p + (size_t)n_h, pad, sizeof pad, hipMemcpyHostToDevice, ctx->stream));
             }
-            hipLaunchKernelGGL(k_halo_fill, dim3(nb), dim3(256), 0, ctx->stream, (const PtF *)d_pts.p, n, gh, cursor.p, d_pts_h.p);
+            hipLaunchKernelGGL(k_halo_fill, dim3(nb), dim3(256), 0, ctx->stream, (const PtF *)d_pts.p, n, gh, cursor.p, d_pts_h.p, d_j_h.p);
             hipLaunchKernelGGL(k_gap_copy, dim3((unsigned)((nc1 + 255) / 256)), dim3(256), 0, ctx->stream,
                                (const uint32_t *)d_counts.p, d_cs_h.p, (int64_t)nc1, g.cs_mask);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(ctx->stream));
-            g.halo = (Real)gh.halo; g.cs_h = d_cs_h.p; g.pts_h = d_pts_h.p;
+            g.halo = (Real)gh.halo; g.cs_h = d_cs_h.p; g.pts_h = d_pts_h.p; g.j_h = d_j_h.p;
         } else {
             d_cs_h.reset();                                   // too many copies for 28-bit offsets: no halo
         }
@@ -496,10 +495,10 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
     // success: hand the index over
     g.seed = d_seed.p;
     *geom = g;
-    *inv_out = d_inv.release();
     *n_h_out = n_h;
     *cs_h_out = d_cs_h.release();
     *pts_h_out = d_pts_h.release();
+    *j_h_out = d_j_h.release();
     *seed_out = d_seed.release();
     *occupied_out = occupied;
     *cell_start_out = d_counts.release();
@@ -526,13 +525,13 @@ pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n,
     const char *he = getenv("PCR_HALO");
     if (he && *he) halo = atof(he);
     return build_grid<float, float, PtF>(ctx, d_xyz, n, h, auto_h, &t->gf, &t->cell_start, &t->cell_seed, &t->pts, &t->occupied,
-                                         &t->inv, halo, &t->cs_h, &t->pts_h, &t->n_h);
+                                         halo, &t->cs_h, &t->pts_h, &t->j_h, &t->n_h);
 }
 
 pcr_status pcr_build_centroid_grid(pcr_context *ctx, const double *d_mean, int64_t n, double cell, pcr_target *t) {
-    uint32_t *cs_h = nullptr; PtF *pts_h = nullptr; int64_t n_h = 0;
+    uint32_t *cs_h = nullptr, *j_h = nullptr; PtF *pts_h = nullptr; int64_t n_h = 0;
     return build_grid<double, double, PtD>(ctx, d_mean, n, cell, false, &t->gd, &t->cell_start, &t->cell_seed, &t->means, &t->occupied,
-                                           &t->inv, 0.0, &cs_h, &pts_h, &n_h);
+                                           0.0, &cs_h, &pts_h, &j_h, &n_h);
 }
 
 // ---- row permutations into cell-sorted order -------------------------------------------------

@@ -440,8 +440,7 @@ __device__ __forceinline__ void nn_tile_loop(const LinArgs &a, Body &&body) {
 }
 
 // one query per lane, every lane on its own (gathers): the general search.  HALO: the target has the
-// extended per-cell lists (ring 0 reads those; the winner's cell-sorted index then comes from the inverse
-// map, one 4-byte gather per query); without them the search tracks the cell-sorted index itself.
+// extended per-cell lists and ring 0 reads those (nn_ring0).
 template <int VOXEL, int SEED, int HALO>
 __device__ __forceinline__ void nn_tile_perlane(const LinArgs &a, const PoseK &P, int64_t first, int64_t end) {
     const int64_t i = first + (threadIdx.x & 63);
@@ -465,7 +464,6 @@ __device__ __forceinline__ void nn_tile_perlane(const LinArgs &a, const PoseK &P
         nn_search<float, PtF, false, true, HALO != 0>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
 #endif
         ok = bo != PCR_NONE && __builtin_sqrtf(best) < a.md_f;
-        if (HALO && ok) bj = nn_sorted_index(a.gf, bo);
     } else {
         double best = a.bound2_d;
         if (SEED && pj != PCR_NONE) nn_test<double, PtD>(a.means[pj], pj, (double)tx, (double)ty, (double)tz, best, bj, bo);
@@ -806,8 +804,12 @@ __device__ __forceinline__ void gn_update(const FinArgs &f, double (*A)[7]) {
     p->iter = it1;
     p->done = done;
     if (f.host_T) {
-        for (int i = 0; i < 16; ++i) f.host_T[i] = T[i];
-        __threadfence_system();
+        // progress word every iteration (the host keeps the queue two iterations ahead of it); the pose
+        // itself crosses PCIe only once, with the final state
+        if (done != PCR_LOOP_RUNNING) {
+            for (int i = 0; i < 16; ++i) f.host_T[i] = T[i];
+            __threadfence_system();
+        }
         *f.host_state = ((unsigned long long)(unsigned)done << 32) | (unsigned)it1;
     }
 }
@@ -815,8 +817,10 @@ __device__ __forceinline__ void gn_update(const FinArgs &f, double (*A)[7]) {
 // the step of the device-resident loop: a 1-wave launch behind the fold (single GPU) or behind the
 // all-reduce of the 29 sums (multi-GPU: every rank computes the same update)
 __global__ void __launch_bounds__(64) k_gn_update(const FinArgs f) {
-    __shared__ double A[6][7];
-    if (threadIdx.x == 0 && f.pose->done == PCR_LOOP_RUNNING) gn_update(f, A);
+    if (threadIdx.x == 0 && f.pose->done == PCR_LOOP_RUNNING) {
+        double A[6][7];                 // registers: gn_solve6 indexes it with compile-time constants only
+        gn_update(f, A);
+    }
 }
 
 // start of pcr_align: the initial pose into HBM (kernel arguments: no host-to-device copy)

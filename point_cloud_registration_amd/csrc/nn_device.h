@@ -50,9 +50,8 @@ __device__ __forceinline__ float dist2_f32(float dx, float dy, float dz) {
 }
 
 // The search tracks (squared distance, original index) -- the oracle's tie rule -- and, for the reduce
-// kernel's gather, the index `j` of the winner in the array it was read from.  Where that index is not
-// wanted (halo searches: the extended lists hold copies, the cell-sorted index comes from Geom::inv
-// instead) the caller passes a dummy `bj` it never reads and the compiler drops that select.
+// kernel's gather, the index `j` of the winner in the array it was read from (the cell-sorted array, or
+// an extended list whose entries are translated through Geom::j_h right after ring 0).
 template <typename Real, typename PT>
 __device__ __forceinline__ void nn_test(const PT &p, uint32_t j, Real qx, Real qy, Real qz,
                                         Real &best, uint32_t &bj, uint32_t &borig) {
@@ -157,8 +156,16 @@ __device__ __forceinline__ int nn_ring0(const Geom<Real> &g, const PT *__restric
     if (gap == 0) {
         const uint32_t s_ = w0 & g.cs_mask, e_ = w1 & g.cs_mask;
         if (STATS) { st->rings++; st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-        nn_scan_range<Real, PT>(ext ? (const PT *)g.pts_h : pts, s_, e_, qx, qy, qz, best, bj, borig);
-        if (ext) c.reach0 = g.halo;
+        if (ext) {
+            // the extended list holds COPIES: track the position in it, then translate the winner to its
+            // cell-sorted index (j_h is laid out like the lists, so neighbouring queries share its lines)
+            uint32_t ej = PCR_NONE;
+            nn_scan_range<Real, PT>((const PT *)g.pts_h, s_, e_, qx, qy, qz, best, ej, borig);
+            if (ej != PCR_NONE) bj = g.j_h[ej];
+            c.reach0 = g.halo;
+        } else {
+            nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
+        }
         return 1;
     }
     if (g.seed) {                                 // a real point nearby bounds the search from the start
@@ -242,8 +249,7 @@ __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restri
 }
 
 // On return: borig = ORIGINAL index of the nearest point (PCR_NONE if nothing closer than
-// sqrt(bound2)), best = its squared distance, bj = its cell-sorted index (HALO searches: undefined,
-// use nn_sorted_index).
+// sqrt(bound2)), best = its squared distance, bj = its cell-sorted index.
 // SEEDED: best / bj / borig come in holding a real target point (any point is an exact upper bound:
 // the search then only has to look inside that radius) or (bound2, PCR_NONE, PCR_NONE).
 template <typename Real, typename PT, bool STATS = false, bool SEEDED = false, bool HALO = false>
@@ -257,7 +263,3 @@ __device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restr
     nn_rings<Real, PT, STATS>(g, pts, cs, c, kstart, qx, qy, qz, best, bj, borig, st);
 }
 
-template <typename Real>
-__device__ __forceinline__ uint32_t nn_sorted_index(const Geom<Real> &g, uint32_t borig) {
-    return borig == PCR_NONE ? PCR_NONE : g.inv[borig];
-}

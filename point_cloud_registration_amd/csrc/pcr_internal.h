@@ -47,14 +47,14 @@ struct Geom {
     // seed[c] (cells with gap > 0 only matter): index of a point in the nearest occupied cell; its
     // distance initialises the search bound of a query that lands in empty space
     const uint32_t *seed;
-    // inv[original index] = cell-sorted index (the search tracks original indices: the oracle's tie rule)
-    const uint32_t *inv;
     // halo (point targets, 0 = none): cs_h / pts_h = per-cell EXTENDED lists, a cell's own points plus the
     // points of its 26 neighbours within `halo` of the shared face / edge / corner; cs_h carries the same
-    // gap bits as cell_start.  Ring 0 scans the extended list and certifies everything within fmin + halo.
+    // gap bits as cell_start; j_h[e] = cell-sorted index of the point copied to pts_h[e].  Ring 0 scans the
+    // extended list and certifies everything within fmin + halo.
     Real halo;
     const uint32_t *cs_h;
     const void *pts_h;
+    const uint32_t *j_h;
 };
 #define PCR_GAP_SHIFT 28
 #define PCR_GAP_MAX 15
@@ -163,9 +163,9 @@ struct pcr_target {
     int64_t occupied = 0;    // occupied cells of the NN grid
     uint32_t *cell_start = nullptr;
     uint32_t *cell_seed = nullptr;
-    uint32_t *inv = nullptr;         // original -> cell-sorted index
     uint32_t *cs_h = nullptr;        // extended (halo) lists of point targets
     PtF *pts_h = nullptr;
+    uint32_t *j_h = nullptr;
     int64_t n_h = 0;                 // records in pts_h
     // point targets
     Geom<float> gf;
