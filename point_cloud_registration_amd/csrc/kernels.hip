@@ -1,25 +1,30 @@
-// Hot-path kernels: transform -> exact NN -> gate -> residual/Jacobian -> 6x6 normal equations.
+// Hot-path kernels: transform -> exact NN -> gate -> residual/Jacobian -> 6x6 normal equations -> (in
+// pcr_align) the Gauss-Newton step itself.
 //
 // One calc_H_g_e2 of the reference (icp.py:24-57, plane_icp.py:30-69,
-// voxelized_plane_icp.py:23-64, ndt.py:24-57) = k_linearize<KIND> + k_finalize.
+// voxelized_plane_icp.py:23-64, ndt.py:24-57) = k_nn_scan + k_reduce_finalize<KIND>  (shipped pipeline;
+// k_linearize + k_finalize, k_reduce + k_finalize and k_nn_coop are kept selectable for A/B runs).
+// One iteration of Registration.align (registration.py:89-111) = that + k_gn_update.
 //
 // Data layout in HBM
 //   scan      SoA x[], y[], z[] float32, Morton-sorted once per align()  -> 3 coalesced dword
-//             streams, 12 B/point, neighbouring lanes are neighbouring points in space
-//   target    cell-sorted float4 {x, y, z, orig idx}; normals float4 in the same order;
-//             cell_start u32[ncells+1]   (voxel targets: double4 means, double[3] normals,
+//             streams, 12 B/point, neighbouring lanes are neighbouring points in space;
+//             nn_j u32[]: the matched cell-sorted index of every scan point (search -> reduce)
+//   target    cell-sorted float4 {x, y, z, orig idx} for the search; cell-sorted 32-byte
+//             {point, normal} records for the PlaneICP gather; cell_start u32[ncells+1]; optional
+//             halo lists (nn_device.h)   (voxel targets: double4 means, double[3] normals,
 //             double[6] inverse covariances; a few MB, L2-resident)
-//   output    per-block partial sums [nblocks][32] double, folded in fixed order by k_finalize
-//             (deterministic: no floating-point atomics anywhere)
+//   output    per-block partial sums [nblocks + 8][32] double, folded in fixed order inside
+//             k_reduce_finalize (deterministic: no floating-point atomics anywhere)
 //
 // Roofline: HBM-bound gather/stream work, no dense contraction -> no MFMA.  Algorithmic bytes
 // per scan point: ICP 24, PlaneICP 36, VPlaneICP 36, NDT 48.
 //
-// Launch: 256-thread blocks (4 waves of 64).  The sorted scan is split into 8 contiguous spans,
-// one per XCD (block b runs on XCD b % 8), so each XCD sweeps one region of space and its
-// private 4 MiB L2 holds that region's target cells (see TileIter).  Per-lane accumulators are float64 (H entries reach 1e11 at 1e8
-// points, float32 would lose the 1e-5 parity bar); the 32 sums are folded across the wave with
-// a halving butterfly (32 shuffles instead of 32 x 6), then across waves through LDS.
+// Launch: 256-thread blocks (4 waves of 64).  The sorted scan is split into contiguous spans per XCD
+// (block b runs on XCD b % 8), so each XCD sweeps one region of space and its private 4 MiB L2 holds
+// that region's target cells (see TileIter / nn_tile_loop).  Per-lane accumulators are float64 (H
+// entries reach 1e11 at 1e8 points, float32 would lose the 1e-5 parity bar); the 32 sums are folded
+// across the wave with a halving butterfly (32 shuffles instead of 32 x 6), then across waves through LDS.
 #include <string.h>
 
 #include "gn_math.h"
@@ -915,7 +920,8 @@ __global__ void __launch_bounds__(256) k_reduce_finalize(const LinArgs a, const 
     __shared__ int role;
     __shared__ double part[8][33];
     __shared__ double tot[32];
-    const int g = (int)(blockIdx.x & 7), per = f.nblocks >> 3;
+    const int ng = 8;          // (a single group for small grids was measured: no gain, 15.9 vs 15.7 us at 100 k points)
+    const int g = (int)(blockIdx.x & 7), per = f.nblocks / ng;
     uint32_t *ctr1 = &f.tickets[g * 16], *ctr2 = &f.tickets[8 * 16];
     double *rows = const_cast<double *>(f.partials);
     // Hand-off protocol (MI355X guide, "sc1 payload -> drained vmcnt -> sc1 flag"): the 32 partial sums
@@ -932,7 +938,7 @@ __global__ void __launch_bounds__(256) k_reduce_finalize(const LinArgs a, const 
     __syncthreads();
     if (!role) return;
 
-    // ---- group leader: rows g + 8 i, i = 0 .. per-1, in a fixed order; 16 loads in flight per thread
+    // ---- group leader: rows g + ng i, i = 0 .. per-1, in a fixed order; 16 loads in flight per thread
     const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
     double s16[16];
 #pragma unroll
@@ -942,7 +948,7 @@ __global__ void __launch_bounds__(256) k_reduce_finalize(const LinArgs a, const 
         for (int u = 0; u < 16; ++u) {
             const int i = i0 + r0 + 8 * u;
             double v = 0.0;
-            if (i < per) v = __hip_atomic_load(&rows[(size_t)(g + 8 * i) * 32 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i < per) v = __hip_atomic_load(&rows[(size_t)(g + ng * i) * 32 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s16[u] += v;
         }
     }
