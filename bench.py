@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--config", default="plane_b01", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-passes", type=int, default=3)
-    ap.add_argument("--variant", type=int, default=None, help="0 fused kernel, 1 NN + reduce kernels")
+    ap.add_argument("--variant", type=int, default=None, help="0 fused kernel, 1 NN + reduce kernels, 2 per launch (default)")
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps passes; the median is reported")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--event-period", type=int, default=3, help="HIP events around every n-th pass")

@@ -185,9 +185,10 @@ PCR_API pcr_status pcr_target_index_halo(pcr_target *t, double *halo, int64_t *r
  * same with each wave's maximum charged to all 64 lanes (the cost under divergence); out[8..10] =
  * wave wall-clock cycles summed over waves: prologue (load, transform, cell), ring 0, outer rings   */
 PCR_API pcr_status pcr_nn_counters(pcr_target *t, pcr_scan *s, const double T[16], double max_dist, double out[11]);
-/* select the hot-path variant: 1 (default) = NN kernel writing correspondences to HBM followed by
- * a reduce kernel that also folds the partial sums; 0 = one fused transform+NN+reduce kernel +
- * a fold kernel (kept for A/B measurements: measured slower on MI355X)                     */
+/* select the hot-path variant: 2 (default) = chosen per launch by the size of the scan: 1 = NN kernel
+ * writing correspondences to HBM followed by a reduce kernel (faster for large scans: twice the
+ * occupancy), 0 = one fused transform+NN+reduce kernel (faster for small, latency-bound scans: 100 k
+ * points 49 vs 59 us per pass); either way the last blocks fold the partial sums inside the kernel   */
 PCR_API pcr_status pcr_set_variant(pcr_context *ctx, int variant);
 PCR_API pcr_status pcr_get_variant(pcr_context *ctx, int *variant);
 /* NN search mode of variant 1: 0 = plain ring search, 1 = start every search from the scan

@@ -52,9 +52,11 @@ extern "C" pcr_status pcr_context_create(int device, pcr_context **out) {
     ctx->device = device;
     ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->stream = stream;
-    ctx->variant = 1;      // measured on MI355X: NN kernel + reduce kernel beats the fused kernel (occupancy)
+    // 2 = per launch: search + reduce kernels for large scans (the fused kernel has half the occupancy),
+    // ONE fused kernel for small, latency-bound ones (measured on MI355X)
+    ctx->variant = 2;
     const char *v = getenv("PCR_VARIANT");
-    if (v) ctx->variant = atoi(v) == 0 ? 0 : 1;
+    if (v && *v) { const int vv = atoi(v); ctx->variant = vv == 0 ? 0 : (vv == 1 ? 1 : 2); }
     const char *nm = getenv("PCR_NN_MODE");
     if (nm && *nm) ctx->nn_mode = atoi(nm);
     const char *ff = getenv("PCR_FUSE_FINALIZE");
@@ -95,7 +97,7 @@ extern "C" pcr_status pcr_context_synchronize(pcr_context *ctx) {
 
 extern "C" pcr_status pcr_set_variant(pcr_context *ctx, int variant) {
     PCR_REQUIRE(ctx, "ctx is NULL");
-    PCR_REQUIRE(variant == 0 || variant == 1, "variant must be 0 or 1");
+    PCR_REQUIRE(variant >= 0 && variant <= 2, "variant must be 0, 1 or 2");
     ctx->variant = variant;
     return PCR_OK;
 }

@@ -316,14 +316,13 @@ struct TileIter {
     }
 };
 
-// ---- variant 0: everything in one kernel ----------------------------------------------------
-template <int KIND>
-__global__ void __launch_bounds__(256) k_linearize(const LinArgs a) {
-    PoseK P;
-    if (!load_pose<true>(a, P)) return;
-    double acc[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+// ---- fused form: everything in one kernel ------------------------------------------------------
+// Slower than search + reduce for large scans (107-157 VGPRs: half the occupancy of k_nn_scan) but FASTER
+// for small ones, where a pass is a chain of dependent cold misses rather than a throughput problem: one
+// launch less, no round trip of the matches through HBM (100 k-point scan: 48.8 vs 58.9 us per pass).
+// The host picks per launch (pcr_set_variant: 2 = automatic, the default).
+template <int KIND, int HALO>
+__device__ __forceinline__ void linearize_body(const LinArgs &a, const PoseK &P, double *acc) {
     const TileIter it(a);
     for (int64_t i = it.base; i < it.end; i += it.stride) {
         const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
@@ -333,7 +332,7 @@ __global__ void __launch_bounds__(256) k_linearize(const LinArgs a) {
         bool ok;
         if (KIND == PCR_ICP || KIND == PCR_PLANE) {
             float best;
-            nn_search<float, PtF>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
+            nn_search<float, PtF, false, false, HALO != 0>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
             ok = bj != PCR_NONE && __builtin_sqrtf(best) < a.md_f;                 // icp.py:34 strict gate
         } else {
             double best;
@@ -342,6 +341,16 @@ __global__ void __launch_bounds__(256) k_linearize(const LinArgs a) {
         }
         if (ok) accumulate<KIND>(acc, a, P, bj, x, y, z, tx, ty, tz);
     }
+}
+
+template <int KIND, int HALO>
+__global__ void __launch_bounds__(256) k_linearize(const LinArgs a) {
+    PoseK P;
+    if (!load_pose<true>(a, P)) return;
+    double acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+    linearize_body<KIND, HALO>(a, P, acc);
     block_store_partials(acc, a.partials);
 }
 
@@ -899,22 +908,14 @@ __global__ void __launch_bounds__(256) k_reduce(const LinArgs a) {
     block_store_partials(acc, a.partials);
 }
 
-// k_reduce with the fold of the partials inside (no separate k_finalize launch: ~10 us and a launch
-// gap per pass).  Any grid that is a multiple of 8 blocks; two levels of tickets.  Blocks g, g+8, g+16, ... form group g (the
-// blocks the dispatcher places on XCD g, so a group's traffic stays in one L2 -- a locality
-// assumption only, every cross-block access is coherent at agent scope).  The block that takes a
-// group's last ticket folds the group's partials into row nblocks+g; the group leader that takes the
-// last of the 8 second-level tickets folds those rows and emits.  8 x (nblocks/8) + 8 serialised
-// atomics instead of nblocks, and no separate k_finalize launch.
-template <int KIND>
-__global__ void __launch_bounds__(256) k_reduce_finalize(const LinArgs a, const FinArgs f) {
-    PoseK P;
-    if (!load_pose<true>(a, P)) return;
-    double acc[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-    const TileIter it(a);
-    reduce_stream<KIND>(acc, a, P, it.base, it.end, it.stride);
+// The fold of the per-block partial sums INSIDE the producing kernel (no separate k_finalize launch: ~10 us
+// and a launch gap per pass).  Any grid that is a multiple of 8 blocks; two levels of tickets.  Blocks g,
+// g+8, g+16, ... form group g (the blocks the dispatcher places on XCD g, so a group's traffic stays in one
+// L2 -- a locality assumption only, every cross-block access is coherent at agent scope).  The block that
+// takes a group's last ticket folds the group's partials into row nblocks+g; the group leader that takes the
+// last of the 8 second-level tickets folds those rows and emits.  8 x (nblocks/8) + 8 serialised atomics
+// instead of nblocks.
+__device__ __forceinline__ void ticket_fold_emit(double *acc, const LinArgs &a, const FinArgs &f) {
     block_store_partials<true>(acc, a.partials);
 
     __shared__ int role;
@@ -980,8 +981,32 @@ __global__ void __launch_bounds__(256) k_reduce_finalize(const LinArgs a, const 
     }
     __syncthreads();
     finalize_emit(f, tot);
+}
+
+// k_reduce with the fold inside (the shipped reduce kernel)
+template <int KIND>
+__global__ void __launch_bounds__(256) k_reduce_finalize(const LinArgs a, const FinArgs f) {
+    PoseK P;
+    if (!load_pose<true>(a, P)) return;
+    double acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+    const TileIter it(a);
+    reduce_stream<KIND>(acc, a, P, it.base, it.end, it.stride);
+    ticket_fold_emit(acc, a, f);
     // (the Gauss-Newton step is NOT inlined here: its straight-line float64 code needs 136 VGPRs, which
     // would cap this streaming kernel at 3 blocks per CU; k_gn_update runs it as a 1-wave launch)
+}
+
+template <int KIND, int HALO>
+__global__ void __launch_bounds__(256) k_linearize_finalize(const LinArgs a, const FinArgs f) {
+    PoseK P;
+    if (!load_pose<true>(a, P)) return;
+    double acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+    linearize_body<KIND, HALO>(a, P, acc);
+    ticket_fold_emit(acc, a, f);
 }
 
 // after the RCCL all-reduce: hand the 29 doubles to the host the same zero-copy way k_finalize does
@@ -1060,7 +1085,8 @@ struct Pass {
     int kind;
     LinArgs a;
     FinArgs f;
-    bool fused_fin;      // k_reduce_finalize instead of k_reduce + k_finalize
+    bool one_kernel;     // fused search + reduce kernel (variant 0, or variant 2 on a small scan)
+    bool fused_fin;      // the fold of the block partials inside the producing kernel instead of k_finalize
     bool seed;           // the scan holds matches against this very target: seed the search with them
 };
 
@@ -1082,11 +1108,15 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
     if (kind == PCR_NDT && !t->vicov) { pcr_set_error("NDT target has no inverse covariances"); return PCR_ERR_NO_TARGET; }
     HIP_TRY(hipSetDevice(ctx->device));
     PCR_TRY(pcr_ensure_scratch(ctx, s->n));
-    if (ctx->variant == 1 && !s->nn_j) {
+    // one fused kernel or search + reduce?  variant 2 (default) decides by size: a small scan is latency-bound
+    // and runs fused (tools/variant_crossover.py: 100 k points 74 vs 80 us per pass, 300 k 97 vs 92, 1.06 M 190 vs 151)
+    bool one_kernel = ctx->variant == 0;
+    if (ctx->variant == 2) one_kernel = s->n <= (int64_t)ctx->num_cu * 1024;   // measured crossover: 200 k - 300 k points on 256 CUs
+    if (!one_kernel && !s->nn_j) {
         HIP_TRY(hipMalloc(&s->nn_j, sizeof(uint32_t) * (size_t)(s->n > 0 ? s->n : 1)));
         s->nn_serial = 0;
     }
-    ps->ctx = ctx; ps->t = t; ps->s = s; ps->kind = kind;
+    ps->ctx = ctx; ps->t = t; ps->s = s; ps->kind = kind; ps->one_kernel = one_kernel;
     LinArgs &a = ps->a;
     memset(&a, 0, sizeof a);
     a.sx = s->x; a.sy = s->y; a.sz = s->z; a.n = s->n;
@@ -1100,12 +1130,12 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
     a.nblocks = choose_blocks(ctx, s->n);
     a.partials = ctx->d_partials;
     a.nn_j = s->nn_j; a.tile_ctr = ctx->d_tile_ctr + 9 * 16;
-    if (ctx->variant == 1 && a.nblocks > ctx->num_cu * 4) a.nblocks = ctx->num_cu * 4;   // k_reduce streams: 4 blocks/CU
+    if (!one_kernel && a.nblocks > ctx->num_cu * 4) a.nblocks = ctx->num_cu * 4;   // k_reduce streams: 4 blocks/CU
     // TileIter and the ticket counts of k_reduce_finalize need a multiple of 8 blocks
     a.nblocks &= ~7;
     if (a.nblocks < 8) a.nblocks = 8;
-    ps->fused_fin = ctx->variant == 1 && ctx->fuse_finalize;
-    ps->seed = ctx->variant == 1 && ctx->nn_mode >= 1 && s->nn_serial == t->serial && s->nn_serial != 0;
+    ps->fused_fin = ctx->fuse_finalize;
+    ps->seed = !one_kernel && ctx->nn_mode >= 1 && s->nn_serial == t->serial && s->nn_serial != 0;
     FinArgs &f = ps->f;
     memset(&f, 0, sizeof f);
     f.partials = ctx->d_partials; f.tile_ctr = ctx->d_tile_ctr + 9 * 16; f.tickets = ctx->d_tile_ctr; f.nblocks = a.nblocks; f.kind = kind; f.out = ctx->d_out;
@@ -1136,14 +1166,25 @@ static pcr_status pass_enqueue(Pass *ps) {
     const dim3 grid(a.nblocks), block(256);
     ProfEvent ev;
     if (ctx->prof_on) ctx->prof_this_pass = (ctx->prof_pass++ % (uint64_t)ctx->prof_period) == 0;
-    if (ctx->variant == 0) {
+    if (ps->one_kernel) {
         pcr_prof_begin(ctx, PCR_K_LINEARIZE, &ev);
-        switch (ps->kind) {
-        case PCR_ICP: hipLaunchKernelGGL(k_linearize<PCR_ICP>, grid, block, 0, ctx->stream, a); break;
-        case PCR_PLANE: hipLaunchKernelGGL(k_linearize<PCR_PLANE>, grid, block, 0, ctx->stream, a); break;
-        case PCR_VPLANE: hipLaunchKernelGGL(k_linearize<PCR_VPLANE>, grid, block, 0, ctx->stream, a); break;
-        default: hipLaunchKernelGGL(k_linearize<PCR_NDT>, grid, block, 0, ctx->stream, a); break;
+        RoctxRange range("pcr:linearize");
+        const bool halo = !ps->t->is_voxel && ps->t->cs_h != nullptr;
+#define PCR_LIN_CASE(K)                                                                                         \
+        if (ps->fused_fin) {                                                                                    \
+            if (halo) hipLaunchKernelGGL((k_linearize_finalize<K, 1>), grid, block, 0, ctx->stream, a, ps->f);  \
+            else hipLaunchKernelGGL((k_linearize_finalize<K, 0>), grid, block, 0, ctx->stream, a, ps->f);       \
+        } else {                                                                                                \
+            if (halo) hipLaunchKernelGGL((k_linearize<K, 1>), grid, block, 0, ctx->stream, a);                  \
+            else hipLaunchKernelGGL((k_linearize<K, 0>), grid, block, 0, ctx->stream, a);                       \
         }
+        switch (ps->kind) {
+        case PCR_ICP: PCR_LIN_CASE(PCR_ICP) break;
+        case PCR_PLANE: PCR_LIN_CASE(PCR_PLANE) break;
+        case PCR_VPLANE: PCR_LIN_CASE(PCR_VPLANE) break;
+        default: PCR_LIN_CASE(PCR_NDT) break;
+        }
+#undef PCR_LIN_CASE
         pcr_prof_end(ctx, &ev);
     } else {
         pcr_prof_begin(ctx, PCR_K_NN, &ev);

@@ -64,11 +64,13 @@ def rel_H(H, Href):
 # what ships and what bench.py times; the others are kept selectable for A/B measurements and must
 # produce the same sums.
 PIPELINES = {
-    "default": dict(variant=1, fuse_finalize=1, nn_mode=0),      # k_nn_scan + k_reduce_finalize
+    "default": dict(variant=2, fuse_finalize=1, nn_mode=0),      # per launch: fused kernel for small scans, search + reduce for large
+    "split": dict(variant=1, fuse_finalize=1, nn_mode=0),        # k_nn_scan + k_reduce_finalize (what large scans run)
     "seeded": dict(variant=1, fuse_finalize=1, nn_mode=1),       # ... search seeded with the previous match
     "coop": dict(variant=1, fuse_finalize=1, nn_mode=2),         # wave-cooperative search (k_nn_coop)
     "unfused": dict(variant=1, fuse_finalize=0, nn_mode=0),      # k_nn_scan + k_reduce + k_finalize
-    "onekernel": dict(variant=0, fuse_finalize=1, nn_mode=0),    # k_linearize + k_finalize
+    "onekernel": dict(variant=0, fuse_finalize=1, nn_mode=0),    # k_linearize_finalize (what small scans run)
+    "onekernel_unfused": dict(variant=0, fuse_finalize=0, nn_mode=0),   # k_linearize + k_finalize
 }
 
 

@@ -128,9 +128,20 @@ def test_linearize_reference_fixture(capi, orc, ctx, g1, name, tag):
 
 
 def test_shipped_pipeline_is_the_default(capi, ctx):
-    """What the library selects on its own is what bench.py times: k_nn_scan + k_reduce_finalize."""
+    """What the library selects on its own is what bench.py times: the per-launch choice between
+    k_nn_scan + k_reduce_finalize (large scans) and k_linearize_finalize (small scans)."""
     from conftest import PIPELINES
     assert ctx.get_pipeline() == PIPELINES["default"]
+    from point_cloud_registration_amd.synthetic import street, perturbed_scan
+    target = street(300_000, seed=1)
+    tgt = capi.Target.points(ctx, target)
+    for n_scan, want in ((20_000, "linearize"), (300_000, "nn")):
+        scan, _ = perturbed_scan(target, n_scan if n_scan < 300_000 else None, seed=3)
+        sc = capi.Scan(ctx, scan)
+        ctx.profile_enable(True); ctx.profile_reset()
+        capi.linearize(tgt, sc, capi.ICP, np.eye(4), 2.0)
+        prof = ctx.profile_read(); ctx.profile_enable(False)
+        assert prof[want][0] == 1 and prof["finalize"][0] == 0, (n_scan, prof)
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -326,8 +337,7 @@ def test_kdtree_seam(capi, orc, g2):
 
 
 def test_profile_counters(capi, ctx, g2, pipeline):
-    """HIP-event launch accounting of each pipeline (the shipped one: 5 NN + 5 reduce launches, no
-    separate fold kernel)."""
+    """HIP-event launch accounting of each pipeline (no separate fold kernel in the shipped ones)."""
     tgt = capi.Target.points(ctx, g2["target"], g2["plane_normals"])
     scan = capi.Scan(ctx, g2["source"])
     ctx.profile_enable(True)
@@ -336,11 +346,13 @@ def test_profile_counters(capi, ctx, g2, pipeline):
         capi.linearize(tgt, scan, capi.PLANE, g2["T"], 0.8)
     prof = ctx.profile_read()
     ctx.profile_enable(False)
-    want = {"default": dict(nn=5, reduce=5, finalize=0, linearize=0),
+    want = {"default": dict(nn=0, reduce=0, finalize=0, linearize=5),          # a 2 k-point scan: the fused kernel
+            "split": dict(nn=5, reduce=5, finalize=0, linearize=0),
             "seeded": dict(nn=5, reduce=5, finalize=0, linearize=0),
             "coop": dict(nn=5, reduce=5, finalize=0, linearize=0),
             "unfused": dict(nn=5, reduce=5, finalize=5, linearize=0),
-            "onekernel": dict(nn=0, reduce=0, finalize=5, linearize=5)}[pipeline]
+            "onekernel": dict(nn=0, reduce=0, finalize=0, linearize=5),
+            "onekernel_unfused": dict(nn=0, reduce=0, finalize=5, linearize=5)}[pipeline]
     assert {k: prof[k][0] for k in want} == want
     assert all(prof[k][1] > 0 for k, v in want.items() if v)
 
