@@ -34,6 +34,46 @@ extern "C" pcr_status pcr_device_count(int *count) {
     return PCR_OK;
 }
 
+// ---- cache of temporaries (pcr_internal.h) ----------------------------------------------------------
+thread_local pcr_context *pcr_tls_ctx = nullptr;
+static const size_t PCR_CACHE_LIMIT = (size_t)1 << 30;        // at most 1 GiB of idle blocks per context
+
+void *pcr_cache_get(pcr_context *ctx, size_t bytes, size_t *cap_out) {
+    // smallest cached block that fits and is not wastefully large (<= 1.5x + 1 MiB)
+    int best = -1;
+    for (int i = 0; i < (int)ctx->cache.size(); ++i) {
+        const size_t c = ctx->cache[i].first;
+        if (c >= bytes && c <= bytes + bytes / 2 + ((size_t)1 << 20) && (best < 0 || c < ctx->cache[best].first)) best = i;
+    }
+    if (best < 0) return nullptr;
+    void *p = ctx->cache[best].second;
+    *cap_out = ctx->cache[best].first;
+    ctx->cache_bytes -= ctx->cache[best].first;
+    ctx->cache[best] = ctx->cache.back();
+    ctx->cache.pop_back();
+    return p;
+}
+
+void pcr_cache_put(pcr_context *ctx, void *p, size_t cap) {
+    if (cap > PCR_CACHE_LIMIT / 2 || ctx->cache.size() >= 256) { (void)hipFree(p); return; }
+    while (ctx->cache_bytes + cap > PCR_CACHE_LIMIT && !ctx->cache.empty()) {     // make room: drop the largest idle block
+        int big = 0;
+        for (int i = 1; i < (int)ctx->cache.size(); ++i) if (ctx->cache[i].first > ctx->cache[big].first) big = i;
+        (void)hipFree(ctx->cache[big].second);
+        ctx->cache_bytes -= ctx->cache[big].first;
+        ctx->cache[big] = ctx->cache.back();
+        ctx->cache.pop_back();
+    }
+    ctx->cache.push_back({cap, p});
+    ctx->cache_bytes += cap;
+}
+
+void pcr_cache_clear(pcr_context *ctx) {
+    for (auto &e : ctx->cache) (void)hipFree(e.second);
+    ctx->cache.clear();
+    ctx->cache_bytes = 0;
+}
+
 // ---- context --------------------------------------------------------------------------------
 extern "C" pcr_status pcr_context_create(int device, pcr_context **out) {
     PCR_REQUIRE(out, "out is NULL");
@@ -70,6 +110,7 @@ extern "C" pcr_status pcr_context_destroy(pcr_context *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     pcr_comm_destroy(ctx);
+    pcr_cache_clear(ctx);
     for (auto &e : ctx->prof_events) { (void)hipEventDestroy(e.start); (void)hipEventDestroy(e.stop); }
     for (auto &e : ctx->prof_free) { (void)hipEventDestroy(e.start); (void)hipEventDestroy(e.stop); }
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
@@ -217,15 +258,12 @@ extern "C" pcr_status pcr_profile_read(pcr_context *ctx, int64_t launches[PCR_K_
 
 // ---- small helpers ---------------------------------------------------------------------------
 template <typename T>
-static pcr_status upload(pcr_context *ctx, const T *host, size_t count, T **dev) {
-    *dev = nullptr;
-    DevBuf<T> buf;
-    HIP_TRY(buf.alloc(count));
+static pcr_status upload(pcr_context *ctx, const T *host, size_t count, DevBuf<T> *buf, bool exact = false) {
+    HIP_TRY(exact ? buf->alloc_exact(count) : buf->alloc(count));
     if (count) {
-        HIP_TRY(hipMemcpyAsync(buf.p, host, sizeof(T) * count, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(buf->p, host, sizeof(T) * count, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
-    *dev = buf.release();
     return PCR_OK;
 }
 
@@ -259,14 +297,11 @@ extern "C" pcr_status pcr_target_points_create(pcr_context *ctx, const float *xy
     PCR_REQUIRE(ctx && out, "NULL argument");
     PCR_REQUIRE(n >= 0 && (xyz || n == 0), "bad point array");
     HIP_TRY(hipSetDevice(ctx->device));
-    float *d_xyz = nullptr, *d_nrm = nullptr;
+    CtxScope scope(ctx);
+    DevBuf<float> d_xyz, d_nrm;
     PCR_TRY(upload<float>(ctx, xyz, (size_t)n * 3, &d_xyz));
-    pcr_status s = PCR_OK;
-    if (normals_or_null) s = upload<float>(ctx, normals_or_null, (size_t)n * 3, &d_nrm);
-    if (s == PCR_OK) s = points_create_common(ctx, d_xyz, n, d_nrm, cell_hint, out);
-    (void)hipFree(d_xyz);
-    if (d_nrm) (void)hipFree(d_nrm);
-    return s;
+    if (normals_or_null) PCR_TRY(upload<float>(ctx, normals_or_null, (size_t)n * 3, &d_nrm));
+    return points_create_common(ctx, d_xyz.p, n, d_nrm.p, cell_hint, out);
 }
 
 extern "C" pcr_status pcr_target_points_create_device(pcr_context *ctx, const float *d_xyz, int64_t n,
@@ -275,6 +310,7 @@ extern "C" pcr_status pcr_target_points_create_device(pcr_context *ctx, const fl
     PCR_REQUIRE(ctx && out, "NULL argument");
     PCR_REQUIRE(n >= 0 && (d_xyz || n == 0), "bad point array");
     HIP_TRY(hipSetDevice(ctx->device));
+    CtxScope scope(ctx);
     return points_create_common(ctx, d_xyz, n, d_normals_or_null, cell_hint, out);
 }
 
@@ -283,8 +319,9 @@ extern "C" pcr_status pcr_target_set_normals(pcr_target *t, const float *normals
     PCR_REQUIRE(!t->is_voxel, "normals belong to point targets");
     pcr_context *ctx = t->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
+    CtxScope scope(ctx);
     DevBuf<float> d_nrm;
-    PCR_TRY(upload<float>(ctx, normals, (size_t)t->n * 3, &d_nrm.p));
+    PCR_TRY(upload<float>(ctx, normals, (size_t)t->n * 3, &d_nrm));
     if (!t->pn) HIP_TRY(hipMalloc(&t->pn, sizeof(PtN) * (size_t)(t->n ? t->n : 1)));
     PCR_TRY(pcr_permute_normals(ctx, d_nrm.p, t->n, t->pts, t->pn));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -305,6 +342,7 @@ extern "C" pcr_status pcr_target_get_normals(pcr_target *t, float *normals_out) 
     pcr_context *ctx = t->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     if (t->n == 0) return PCR_OK;
+    CtxScope scope(ctx);
     DevBuf<float> d_out;
     HIP_TRY(d_out.alloc(3 * (size_t)t->n));
     hipLaunchKernelGGL(k_unpermute_normals, dim3((unsigned)((t->n + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -345,9 +383,12 @@ extern "C" pcr_status pcr_target_voxels_create_from_stats(pcr_context *ctx, cons
     HIP_TRY(hipSetDevice(ctx->device));
     pcr_target *t = new pcr_target();
     t->ctx = ctx; t->is_voxel = 1; t->n = n_v; t->serial = ctx->next_serial++;
-    pcr_status s = upload<double>(ctx, mean, (size_t)n_v * 3, &t->st_mean);
-    if (s == PCR_OK && norm_or_null) s = upload<double>(ctx, norm_or_null, (size_t)n_v * 3, &t->st_norm);
-    if (s == PCR_OK && icov_or_null) s = upload<double>(ctx, icov_or_null, (size_t)n_v * 9, &t->st_icov);
+    CtxScope scope(ctx);
+    DevBuf<double> b_mean, b_norm, b_icov;
+    pcr_status s = upload<double>(ctx, mean, (size_t)n_v * 3, &b_mean, true);
+    if (s == PCR_OK && norm_or_null) s = upload<double>(ctx, norm_or_null, (size_t)n_v * 3, &b_norm, true);
+    if (s == PCR_OK && icov_or_null) s = upload<double>(ctx, icov_or_null, (size_t)n_v * 9, &b_icov, true);
+    t->st_mean = b_mean.release(); t->st_norm = b_norm.release(); t->st_icov = b_icov.release();
     if (s == PCR_OK) s = pcr_voxel_target_finish(ctx, t, voxel_size);
     if (s != PCR_OK) { target_free(t); return s; }
     *out = t;
@@ -413,6 +454,7 @@ extern "C" pcr_status pcr_scan_create_device(pcr_context *ctx, const float *d_xy
                                              pcr_scan **out) {
     PCR_REQUIRE(ctx && out, "NULL argument");
     PCR_REQUIRE(n >= 0 && (d_xyz || n == 0), "bad scan array");
+    CtxScope scope(ctx);
     pcr_scan *s = new pcr_scan();
     s->ctx = ctx;
     pcr_status st = pcr_sort_scan(ctx, d_xyz, n, flags, s);
@@ -425,11 +467,10 @@ extern "C" pcr_status pcr_scan_create(pcr_context *ctx, const float *xyz, int64_
     PCR_REQUIRE(ctx && out, "NULL argument");
     PCR_REQUIRE(n >= 0 && (xyz || n == 0), "bad scan array");
     HIP_TRY(hipSetDevice(ctx->device));
-    float *d_xyz = nullptr;
+    CtxScope scope(ctx);
+    DevBuf<float> d_xyz;
     PCR_TRY(upload<float>(ctx, xyz, (size_t)n * 3, &d_xyz));
-    pcr_status s = pcr_scan_create_device(ctx, d_xyz, n, flags, out);
-    (void)hipFree(d_xyz);
-    return s;
+    return pcr_scan_create_device(ctx, d_xyz.p, n, flags, out);
 }
 
 extern "C" pcr_status pcr_scan_size(pcr_scan *s, int64_t *n) {
@@ -502,29 +543,24 @@ static pcr_status nn_query_common(pcr_target *t, const float *q, int64_t m, doub
     pcr_context *ctx = t->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     if (m == 0) return PCR_OK;
-    float *d_q = nullptr;
+    CtxScope scope(ctx);
+    DevBuf<float> d_q;
     PCR_TRY(upload<float>(ctx, q, (size_t)m * 3, &d_q));
-    void *d_dist = nullptr;
-    int64_t *d_idx = nullptr;
     const size_t ds = f64 ? 8 : 4;
-    pcr_status s = PCR_OK;
-    if (hipMalloc(&d_dist, ds * (size_t)m) != hipSuccess || hipMalloc(&d_idx, 8 * (size_t)m) != hipSuccess) {
+    DevBuf<char> d_dist;
+    DevBuf<int64_t> d_idx;
+    if (d_dist.alloc_bytes(ds * (size_t)m) != hipSuccess || d_idx.alloc((size_t)m) != hipSuccess) {
         pcr_set_error("hipMalloc failed for %lld query results", (long long)m);
-        s = PCR_ERR_NOMEM;
+        return PCR_ERR_NOMEM;
     }
-    if (s == PCR_OK) s = pcr_run_nn(t, d_q, m, r_max, d_dist, d_idx, f64);
-    if (s == PCR_OK) {
-        if (hipMemcpyAsync(dist, d_dist, ds * (size_t)m, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipMemcpyAsync(idx, d_idx, 8 * (size_t)m, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess) {
-            pcr_set_error("copy-back of query results failed: %s", hipGetErrorString(hipGetLastError()));
-            s = PCR_ERR_HIP;
-        }
+    PCR_TRY(pcr_run_nn(t, d_q.p, m, r_max, d_dist.p, d_idx.p, f64));
+    if (hipMemcpyAsync(dist, d_dist.p, ds * (size_t)m, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(idx, d_idx.p, 8 * (size_t)m, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        pcr_set_error("copy-back of query results failed: %s", hipGetErrorString(hipGetLastError()));
+        return PCR_ERR_HIP;
     }
-    (void)hipFree(d_q);
-    if (d_dist) (void)hipFree(d_dist);
-    if (d_idx) (void)hipFree(d_idx);
-    return s;
+    return PCR_OK;
 }
 
 extern "C" pcr_status pcr_nn_query(pcr_target *t, const float *q, int64_t m, float r_max, float *dist, int64_t *idx) {

@@ -267,7 +267,7 @@ static pcr_status pack_gap_field(pcr_context *ctx, uint32_t *cs, int nx, int ny,
     DevBuf<uint32_t> s1, s2, seed;
     HIP_TRY(g1.alloc((size_t)ncells)); HIP_TRY(g2.alloc((size_t)ncells));
     HIP_TRY(s1.alloc((size_t)ncells)); HIP_TRY(s2.alloc((size_t)ncells));
-    HIP_TRY(seed.alloc((size_t)ncells));
+    HIP_TRY(seed.alloc_exact((size_t)ncells));
     const unsigned nb = (unsigned)((ncells + 255) / 256);
     hipLaunchKernelGGL(k_gap_x, dim3(nb), dim3(256), 0, ctx->stream, (const uint32_t *)cs, nx, ncells, g1.p, s1.p);
     hipLaunchKernelGGL(k_gap_axis, dim3(nb), dim3(256), 0, ctx->stream, (const uint8_t *)g1.p, (const uint32_t *)s1.p, ncells,
@@ -403,14 +403,14 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
     make_geom<Real>(lo, hi, h, &g, &ncells);
     while (ncells > max_cells) { h *= 2.0; make_geom<Real>(lo, hi, h, &g, &ncells); }
     *geom = g;
-    HIP_TRY(d_counts.alloc((size_t)ncells + 1));
+    HIP_TRY(d_counts.alloc_exact((size_t)ncells + 1));
     HIP_TRY(hipMemsetAsync(d_counts.p, 0, sizeof(uint32_t) * ((size_t)ncells + 1), ctx->stream));
     DevBuf<uint32_t> d_cid, d_idx, d_cid2, d_idx2, d_seed;
     const size_t nn = (size_t)(n > 0 ? n : 1);
     HIP_TRY(d_cid.alloc(nn)); HIP_TRY(d_idx.alloc(nn));
     HIP_TRY(d_cid2.alloc(nn)); HIP_TRY(d_idx2.alloc(nn));
     DevBuf<PT> d_pts;
-    HIP_TRY(d_pts.alloc(nn + PCR_PTS_PAD));
+    HIP_TRY(d_pts.alloc_exact(nn + PCR_PTS_PAD));
     {   // sentinel records behind the last point (see nn_scan_range): +inf coordinates, index ~0
         PT pad[PCR_PTS_PAD];
         for (int i = 0; i < PCR_PTS_PAD; ++i) {
@@ -459,7 +459,7 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
         memcpy(&gh, &g, sizeof gh);                           // Real == float here
         gh.halo = (float)(fmin(halo_frac, 0.45) * (double)g.h);
         const size_t nc1 = (size_t)ncells + 1;
-        HIP_TRY(d_cs_h.alloc(nc1));
+        HIP_TRY(d_cs_h.alloc_exact(nc1));
         HIP_TRY(hipMemsetAsync(d_cs_h.p, 0, sizeof(uint32_t) * nc1, ctx->stream));
         hipLaunchKernelGGL(k_halo_count, dim3(nb), dim3(256), 0, ctx->stream, (const PtF *)d_pts.p, n, gh, d_cs_h.p);
         HIP_TRY(hipGetLastError());
@@ -472,8 +472,8 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
             DevBuf<uint32_t> cursor;
             HIP_TRY(cursor.alloc(nc1));
             HIP_TRY(hipMemcpyAsync(cursor.p, d_cs_h.p, sizeof(uint32_t) * nc1, hipMemcpyDeviceToDevice, ctx->stream));
-            HIP_TRY(d_pts_h.alloc((size_t)n_h + PCR_PTS_PAD));
-            HIP_TRY(d_j_h.alloc((size_t)n_h + PCR_PTS_PAD));
+            HIP_TRY(d_pts_h.alloc_exact((size_t)n_h + PCR_PTS_PAD));
+            HIP_TRY(d_j_h.alloc_exact((size_t)n_h + PCR_PTS_PAD));
             {
                 PtF pad[PCR_PTS_PAD];
                 for (int i = 0; i < PCR_PTS_PAD; ++i) {

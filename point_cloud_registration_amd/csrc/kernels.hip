@@ -1437,6 +1437,7 @@ extern "C" pcr_status pcr_nn_counters(pcr_target *t, pcr_scan *s, const double T
     a.bound2_f = (float)(bound * bound);
     a.nblocks = choose_blocks(ctx, s->n);
     unsigned long long h[11];
+    CtxScope scope(ctx);
     DevBuf<unsigned long long> d;
     HIP_TRY(d.alloc(11));
     HIP_TRY(hipMemsetAsync(d.p, 0, sizeof h, ctx->stream));

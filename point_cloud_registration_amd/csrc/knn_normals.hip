@@ -191,6 +191,7 @@ extern "C" pcr_status pcr_knn_query(pcr_target *t, const float *q, int64_t m, in
     pcr_context *ctx = t->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     if (m == 0) return PCR_OK;
+    CtxScope scope(ctx);
     DevBuf<float> d_q, d_dist;
     DevBuf<int64_t> d_idx;
     HIP_TRY(d_q.alloc(3 * (size_t)m));

@@ -119,67 +119,59 @@ static pcr_status voxel_build(pcr_context *ctx, const T *d_xyz, int64_t n, doubl
                               pcr_target *t) {
     const size_t nn = (size_t)(n > 0 ? n : 1);
     const unsigned nb = (unsigned)((n + 255) / 256);
-    long long *k1 = nullptr, *k2 = nullptr, *ukeys = nullptr;
-    uint32_t *i1 = nullptr, *i2 = nullptr, *counts = nullptr, *seg = nullptr, *flags = nullptr;
-    int *d_runs = nullptr;
-    void *tmp = nullptr;
-    pcr_status st = PCR_OK;
+    // temporaries: blocks of the context's cache (DevBuf), gone on every exit path
+    DevBuf<long long> k1, k2, ukeys;
+    DevBuf<uint32_t> i1, i2, counts, seg, flags;
+    DevBuf<int> d_runs;
+    DevBuf<char> tmp;
     int64_t nu = 0, nk = 0;
-#define VB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { pcr_set_error("%s failed: %s", #expr, hipGetErrorString(e_)); st = PCR_ERR_HIP; goto done; } } while (0)
-    VB_TRY(hipMalloc(&k1, 8 * nn)); VB_TRY(hipMalloc(&k2, 8 * nn)); VB_TRY(hipMalloc(&ukeys, 8 * nn));
-    VB_TRY(hipMalloc(&i1, 4 * nn)); VB_TRY(hipMalloc(&i2, 4 * nn));
-    VB_TRY(hipMalloc(&counts, 4 * (nn + 1))); VB_TRY(hipMalloc(&seg, 4 * (nn + 1))); VB_TRY(hipMalloc(&flags, 4 * (nn + 1)));
-    VB_TRY(hipMalloc(&d_runs, sizeof(int)));
+    HIP_TRY(k1.alloc(nn)); HIP_TRY(k2.alloc(nn)); HIP_TRY(ukeys.alloc(nn));
+    HIP_TRY(i1.alloc(nn)); HIP_TRY(i2.alloc(nn));
+    HIP_TRY(counts.alloc(nn + 1)); HIP_TRY(seg.alloc(nn + 1)); HIP_TRY(flags.alloc(nn + 1));
+    HIP_TRY(d_runs.alloc(1));
     if (n > 0) {
-        hipLaunchKernelGGL(k_voxel_keys<T>, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, (T)voxel_size, k1, i1);
+        hipLaunchKernelGGL(k_voxel_keys<T>, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, (T)voxel_size, k1.p, i1.p);
         size_t tb = 0;
-        VB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k1, k2, i1, i2, (int)n, 0, 64, ctx->stream));
-        VB_TRY(hipMalloc(&tmp, tb ? tb : 16));
-        VB_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, k1, k2, i1, i2, (int)n, 0, 64, ctx->stream));
-        VB_TRY(hipStreamSynchronize(ctx->stream));
-        VB_TRY(hipFree(tmp)); tmp = nullptr;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k1.p, k2.p, i1.p, i2.p, (int)n, 0, 64, ctx->stream));
+        HIP_TRY(tmp.alloc_bytes(tb));
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k1.p, k2.p, i1.p, i2.p, (int)n, 0, 64, ctx->stream));
         tb = 0;
-        VB_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb, k2, ukeys, counts, d_runs, (int)n, ctx->stream));
-        VB_TRY(hipMalloc(&tmp, tb ? tb : 16));
-        VB_TRY(hipcub::DeviceRunLengthEncode::Encode(tmp, tb, k2, ukeys, counts, d_runs, (int)n, ctx->stream));
+        HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb, k2.p, ukeys.p, counts.p, d_runs.p, (int)n, ctx->stream));
+        DevBuf<char> tmp2;
+        HIP_TRY(tmp2.alloc_bytes(tb));
+        HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(tmp2.p, tb, k2.p, ukeys.p, counts.p, d_runs.p, (int)n, ctx->stream));
         int runs = 0;
-        VB_TRY(hipMemcpyAsync(&runs, d_runs, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        VB_TRY(hipStreamSynchronize(ctx->stream));
-        VB_TRY(hipFree(tmp)); tmp = nullptr;
+        HIP_TRY(hipMemcpyAsync(&runs, d_runs.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
         nu = runs;
         // segment starts (exclusive scan of counts) and compacted positions of the kept voxels
-        VB_TRY(hipMemsetAsync(counts + nu, 0, 4, ctx->stream));
+        HIP_TRY(hipMemsetAsync(counts.p + nu, 0, 4, ctx->stream));
         tb = 0;
-        VB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, counts, seg, (int)nu + 1, ctx->stream));
-        VB_TRY(hipMalloc(&tmp, tb ? tb : 16));
-        VB_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tb, counts, seg, (int)nu + 1, ctx->stream));
-        hipLaunchKernelGGL(k_keep_flags, dim3((unsigned)((nu + 256) / 256)), dim3(256), 0, ctx->stream, counts, nu, min_points, flags);
-        VB_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tb, flags, flags, (int)nu + 1, ctx->stream));
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, counts.p, seg.p, (int)nu + 1, ctx->stream));
+        DevBuf<char> tmp3;
+        HIP_TRY(tmp3.alloc_bytes(tb));
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp3.p, tb, counts.p, seg.p, (int)nu + 1, ctx->stream));
+        hipLaunchKernelGGL(k_keep_flags, dim3((unsigned)((nu + 256) / 256)), dim3(256), 0, ctx->stream, counts.p, nu, min_points, flags.p);
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp3.p, tb, flags.p, flags.p, (int)nu + 1, ctx->stream));
         uint32_t kept = 0;
-        VB_TRY(hipMemcpyAsync(&kept, flags + nu, 4, hipMemcpyDeviceToHost, ctx->stream));
-        VB_TRY(hipStreamSynchronize(ctx->stream));
-        VB_TRY(hipFree(tmp)); tmp = nullptr;
+        HIP_TRY(hipMemcpyAsync(&kept, flags.p + nu, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
         nk = kept;
     }
     {
         const size_t kk = (size_t)(nk > 0 ? nk : 1);
-        VB_TRY(hipMalloc(&t->st_mean, 8 * 3 * kk)); VB_TRY(hipMalloc(&t->st_cov, 8 * 9 * kk));
-        VB_TRY(hipMalloc(&t->st_norm, 8 * 3 * kk)); VB_TRY(hipMalloc(&t->st_icov, 8 * 9 * kk));
-        VB_TRY(hipMalloc(&t->st_counts, 8 * kk)); VB_TRY(hipMalloc(&t->st_keys, 8 * kk));
+        HIP_TRY(hipMalloc(&t->st_mean, 8 * 3 * kk)); HIP_TRY(hipMalloc(&t->st_cov, 8 * 9 * kk));
+        HIP_TRY(hipMalloc(&t->st_norm, 8 * 3 * kk)); HIP_TRY(hipMalloc(&t->st_icov, 8 * 9 * kk));
+        HIP_TRY(hipMalloc(&t->st_counts, 8 * kk)); HIP_TRY(hipMalloc(&t->st_keys, 8 * kk));
         if (nu > 0) {
-            hipLaunchKernelGGL(k_voxel_stats<T>, dim3((unsigned)((nu + 3) / 4)), dim3(256), 0, ctx->stream, d_xyz, i2,
-                               ukeys, counts, seg, flags, nu, min_points, t->st_mean, t->st_cov, t->st_norm, t->st_icov,
+            hipLaunchKernelGGL(k_voxel_stats<T>, dim3((unsigned)((nu + 3) / 4)), dim3(256), 0, ctx->stream, d_xyz, i2.p,
+                               ukeys.p, counts.p, seg.p, flags.p, nu, min_points, t->st_mean, t->st_cov, t->st_norm, t->st_icov,
                                t->st_counts, t->st_keys);
-            VB_TRY(hipGetLastError());
-            VB_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
         }
         t->n = nk;
     }
-done:
-#undef VB_TRY
-    void *ptrs[] = {k1, k2, ukeys, i1, i2, counts, seg, flags, d_runs, tmp};
-    for (void *p : ptrs) if (p) (void)hipFree(p);
-    if (st != PCR_OK) return st;
     return pcr_voxel_target_finish(ctx, t, voxel_size);
 }
 
@@ -190,6 +182,7 @@ extern "C" pcr_status pcr_target_voxels_create(pcr_context *ctx, const void *xyz
     PCR_REQUIRE(n < ((int64_t)1 << 31), "at most 2^31-1 points per target");
     PCR_REQUIRE(voxel_size > 0, "voxel_size must be positive");
     HIP_TRY(hipSetDevice(ctx->device));
+    CtxScope scope(ctx);
     const size_t elem = xyz_is_f64 ? 8 : 4;
     DevBuf<char> d_xyz;
     HIP_TRY(d_xyz.alloc_bytes(elem * 3 * (size_t)(n > 0 ? n : 1)));

@@ -16,5 +16,6 @@ for n in [int(float(a)) for a in (sys.argv[1:] or ["1.06e6", "1e7"])]:
     t3 = time.perf_counter(); v = _capi.Target.voxels(ctx, pts, 1.0, 10); ctx.synchronize(); t4 = time.perf_counter()
     nv = v.size(); v.close()
     sc0 = time.perf_counter(); s = _capi.Scan(ctx, pts[: min(n, 12_500_000)]); ctx.synchronize(); sc1 = time.perf_counter(); s.close()
-    print(f"n={n}: point index {t1 - t0:.3f} s (cell {info['cell']:.3f}, dims {info['dims']}), normals k=15 {t2 - t1:.3f} s, "
-          f"voxel build {t4 - t3:.3f} s ({nv} voxels), scan upload+sort {sc1 - sc0:.3f} s", flush=True)
+    print(f"n={n}: point index {1e3 * (t1 - t0):.2f} ms (cell {info['cell']:.3f}, dims {info['dims']}, halo records {info['halo_records']}), "
+          f"normals k=15 {1e3 * (t2 - t1):.2f} ms, voxel build {1e3 * (t4 - t3):.2f} ms ({nv} voxels), "
+          f"scan upload+sort {1e3 * (sc1 - sc0):.2f} ms", flush=True)
