@@ -1236,7 +1236,7 @@ static pcr_status pass_enqueue(Pass *ps) {
     return PCR_OK;
 }
 
-// spin on a word in pinned host memory that a kernel writes, then fall back to a blocking wait
+// Spin on a word in pinned host memory that a kernel writes, then fall back to a blocking wait.
 template <typename Pred>
 static pcr_status wait_host_word(pcr_context *ctx, Pred ready, const char *what) {
     for (long spin = 0; spin < 4000000L; ++spin) {
@@ -1247,6 +1247,16 @@ static pcr_status wait_host_word(pcr_context *ctx, Pred ready, const char *what)
     if (!ready()) { pcr_set_error("%s did not report completion", what); return PCR_ERR_HIP; }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     return PCR_OK;
+}
+
+// The zero-copy hand-off never calls into the HIP runtime between launches, so the runtime never gets
+// to retire finished commands.  Observed (tools/stall_probe.py): about once per 1500 unprofiled passes,
+// mostly early in a process, ONE call blocks for 12-42 ms -- not in the spin above (it returns within
+// microseconds) but in a launch; never seen with HIP events around the passes (they retire commands as
+// they go).  Every 8th pass the idle stream is queried (~1 us): the stalls became ~10x rarer (1 in
+// 18 000 passes), not impossible; bench.py's median over blocks is immune either way.
+static void retire_completed(pcr_context *ctx) {
+    if ((++ctx->passes_since_query & 7u) == 0) (void)hipStreamQuery(ctx->stream);
 }
 
 pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double T[16], double max_dist,
@@ -1284,6 +1294,7 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
     if (flagged) {
         PCR_TRY(wait_host_word(ctx, [&] { return *flag == seq; }, "finalize kernel"));
         for (int i = 0; i < 29; ++i) out[i] = ctx->h_out[i];
+        retire_completed(ctx);
         return PCR_OK;
     }
     HIP_TRY(hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(double) * 29, hipMemcpyDeviceToHost, ctx->stream));
@@ -1341,6 +1352,7 @@ pcr_status pcr_run_align(pcr_target *t, pcr_scan *s, int kind, const double T_in
             if (loop_done() != PCR_LOOP_RUNNING) break;
             const int fin = passes_done();
             if (enq < max_iter && enq < fin + AHEAD) {
+                retire_completed(ctx);
                 PCR_TRY(pass_enqueue(&ps));
                 hipLaunchKernelGGL(k_gn_update, dim3(1), dim3(64), 0, ctx->stream, f);
                 HIP_TRY(hipGetLastError());

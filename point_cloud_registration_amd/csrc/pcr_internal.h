@@ -171,6 +171,7 @@ struct pcr_context {
     double *h_out = nullptr;        // pinned + mapped: 32 doubles, then the completion sequence number
     double *h_out_dev = nullptr;    // device-side address of h_out
     uint32_t seq = 0;
+    uint32_t passes_since_query = 0;   // see retire_completed (kernels.hip)
     // device-resident Gauss-Newton loop: pose in HBM, per-iteration trace rows (16 + 29 doubles),
     // progress words in pinned host memory ([0] iter, [1] done, then 16 doubles of pose)
     PoseDev *d_pose = nullptr;
