@@ -245,6 +245,55 @@ def test_align_matches_reference(capi, g2, name, loop, pipeline):
     assert rel_H(H, g2[f"T_{name}_H"]) < TOL_REF
 
 
+def test_align_loop_edge_cases(capi, orc, ctx, g2):
+    """pcr_align's device-resident loop against its host-driven form: max_iter 0 / 1 / exhausted, a tolerance
+    met at the first pass (quirk Q4: the step is discarded), the trace rows, every kind."""
+    gt, ot = make_targets(capi, orc, ctx, g2["target"], g2["plane_normals"], float(g2["voxel_size"]))
+    md = float(g2["max_dist"])
+    scan = capi.Scan(ctx, g2["source"])
+    T0 = np.array(g2["T"])
+    for name in NAMES:
+        kind = kind_of(capi, name)
+        for max_iter, tol in ((0, 1e-3), (1, 1e-3), (2, 1e-3), (3, 1e9), (30, 1e-3)):
+            Td, itd, trd = capi.align(gt[name], scan, kind, T0, max_iter, tol, md, want_trace=True)
+            Th, ith, trh = capi.align(gt[name], scan, kind, T0, max_iter, tol, md,
+                                      capi.FLAG_ICP_RR_QUIRK | capi.FLAG_HOST_LOOP, want_trace=True)
+            assert itd == ith and np.array_equal(Td, Th) and np.array_equal(trd, trh), (name, max_iter, tol)
+            if max_iter == 0:
+                assert itd == 0 and np.array_equal(Td, T0)
+            if tol == 1e9:
+                assert itd == 1 and np.array_equal(Td, T0)          # converged at once: pose untouched
+            if max_iter in (1, 2):
+                assert itd == max_iter
+        # the trace's first row is the pass at T0: the oracle's sums
+        Ho, go, e2o, cnto = orc.calc_H_g_e2(kind, ot[name], T0, g2["source"], md, with_count=True)
+        Hg, gg, e2g, cntg = capi.unpack29(trd[0, 16:])
+        assert cntg == cnto and rel_H(Hg, Ho) < TOL_ORC and np.array_equal(trd[0, :16].reshape(4, 4), T0)
+
+
+def test_no_device_memory_growth(capi, ctx, g2):
+    """Targets, scans, voxel builds, k-NN queries created and destroyed in a loop: the per-context cache of
+    temporaries is bounded and nothing leaks."""
+    import torch
+    import point_cloud_registration_amd as pcr
+
+    def cycle():
+        for cls, kw in ((pcr.ICP, {}), (pcr.PlaneICP, {"k": 8}), (pcr.VPlaneICP, {}), (pcr.NDT, {})):
+            m = cls(max_dist=float(g2["max_dist"]), **kw)
+            m.set_target(g2["target"]); m.align(g2["source"]); m.calc_H_g_e2(np.eye(4), g2["source"])
+        tree = pcr.KDTree(g2["target"]); tree.query(g2["source"][:100]); tree.query(g2["source"][:50], k=5)
+        pcr.voxel_filter(g2["target"], 0.5)
+
+    import gc
+    cycle(); gc.collect(); ctx.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for _ in range(10):
+        cycle()
+    gc.collect(); ctx.synchronize()
+    free1 = torch.cuda.mem_get_info(0)[0]
+    assert free0 - free1 < 8 * 2 ** 20, (free0 - free1) / 2 ** 20
+
+
 def test_zero_correspondences_is_singular(g2):
     """Quirk Q7: nothing passes the gate -> H = 0 -> numpy.linalg.LinAlgError."""
     import point_cloud_registration_amd as pcr
