@@ -77,14 +77,34 @@ def parse():
 
 
 def kernel_source_hash():
-    """Identity of the kernels a PMC profile was collected on: sha1 over the HIP sources."""
+    """Identity of the kernels a PMC profile was collected on: sha1 of the DEVICE code of libpcr_hip.so (its
+    .hip_fatbin section: unchanged by host-only edits), or of the HIP sources when the library is not built."""
+    import struct
+    lib = os.path.join(REPO, "point_cloud_registration_amd", "libpcr_hip.so")
+    try:
+        with open(lib, "rb") as f:
+            data = f.read()
+        assert data[:4] == b"\x7fELF" and data[4] == 2
+        shoff, = struct.unpack_from("<Q", data, 0x28)
+        shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+        def sec(i):
+            name, typ, flags, addr, off, size = struct.unpack_from("<IIQQQQ", data, shoff + i * shentsize)
+            return name, off, size
+        _, stroff, strsize = sec(shstrndx)
+        for i in range(shnum):
+            name, off, size = sec(i)
+            end = data.index(b"\0", stroff + name)
+            if data[stroff + name:end] == b".hip_fatbin":
+                return "fatbin:" + hashlib.sha1(data[off:off + size]).hexdigest()[:16]
+    except Exception:
+        pass
     h = hashlib.sha1()
     d = os.path.join(REPO, "point_cloud_registration_amd", "csrc")
     for name in sorted(os.listdir(d)):
         if name.endswith((".hip", ".h")):
             h.update(name.encode())
             h.update(open(os.path.join(d, name), "rb").read())
-    return h.hexdigest()[:16]
+    return "src:" + h.hexdigest()[:16]
 
 
 def make_cloud(n, seed):

@@ -1253,10 +1253,11 @@ static pcr_status wait_host_word(pcr_context *ctx, Pred ready, const char *what)
 // to retire finished commands.  Observed (tools/stall_probe.py): about once per 1500 unprofiled passes,
 // mostly early in a process, ONE call blocks for 12-42 ms -- not in the spin above (it returns within
 // microseconds) but in a launch; never seen with HIP events around the passes (they retire commands as
-// they go).  Every 8th pass the idle stream is queried (~1 us): the stalls became ~10x rarer (1 in
-// 18 000 passes), not impossible; bench.py's median over blocks is immune either way.
+// they go).  Querying the idle stream every 8th pass made the stalls ~10x rarer (1 in 18 000 passes) but a
+// query turned out to cost ~50 us (+4 % on a 1.06 M-point pass); it is done every 64th pass (< 1 us per
+// pass).  bench.py's median over blocks is immune either way; ms_per_step_max shows a stall when one hits.
 static void retire_completed(pcr_context *ctx) {
-    if ((++ctx->passes_since_query & 7u) == 0) (void)hipStreamQuery(ctx->stream);
+    if ((++ctx->passes_since_query & 63u) == 0) (void)hipStreamQuery(ctx->stream);
 }
 
 pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double T[16], double max_dist,
