@@ -388,10 +388,11 @@ __global__ void __launch_bounds__(256) k_linearize(const LinArgs a) {
 // calls body(first, end) wave-uniformly for every 64-point tile this wave is given: lane l owns scan
 // point first + l, which exists iff first + l < end
 // Two hand-out policies, chosen per launch (LinArgs::sched_local):
-//  * block-local (small scans: at most ~1.5 tiles per resident wave): the XCD's span is dealt round-robin
-//    to the XCD's blocks (block b owns tiles b, b + B, ...) and a block's four waves pull from that list
-//    through ONE counter in LDS -- no global atomics (they alone cost 24 us of a 1.06 M-point pass and
-//    ~10 us of a 100 k-point one).  Measured: 100 k-point scan 38.8 -> 30.6 us.
+//  * block-local (mid-size scans: at most ~1.5 tiles per launched wave, i.e. up to ~590 k points; below
+//    ~262 k the fused kernel runs instead): the XCD's span is dealt round-robin to the XCD's blocks (block
+//    b owns tiles b, b + B, ...) and a block's four waves pull from that list through ONE counter in LDS --
+//    no global atomics (they alone cost 24 us of a 1.06 M-point pass).  Measured per pass: 300 k points
+//    91.7 vs 104.8 us, 450 k 105.5 vs 118.8.
 //  * global counters (everything larger): PCR_TILE_CTRS sub-spans, one static round, then device-wide
 //    counters.  With many tiles per wave and costs that differ 10x between regions the static deal
 //    loses more than the atomics cost (1.06 M: 134 vs 147 us; 1e8-point target: 3.3 vs 4.9 ms).
