@@ -27,5 +27,20 @@ while time.time() - t0 < seconds:
         if not np.array_equal(a, b) or not np.isfinite(a).all() or a[28] > n:
             print("MISMATCH", n, kind, a[:3], b[:3], a[28], b[28]); sys.exit(1)
         passes += 2
+        if passes % 20 == 0:                    # the other kernel pipelines: same correspondences, same sums up to summation order
+            for pipe in (dict(variant=0), dict(variant=1), dict(variant=1, nn_mode=1), dict(variant=1, nn_mode=2), dict(variant=1, fuse_finalize=0)):
+                with ctx.pipeline(**pipe):
+                    c = _capi.linearize(tgt, sc, kind, T, 2.0)
+                if c[28] != a[28] or not np.allclose(c, a, rtol=1e-10, atol=1e-9 * max(np.max(np.abs(a)), 1.0)):
+                    print("PIPELINE MISMATCH", pipe, n, kind, a[:3], c[:3], a[28], c[28]); sys.exit(1)
+                passes += 1
+        if passes % 50 == 0 and n > 100:        # device-resident loop == host-driven loop, bit for bit
+            try:
+                Td, itd = _capi.align(tgt, sc, kind, T, 10, 1e-3, 2.0)
+                Th, ith = _capi.align(tgt, sc, kind, T, 10, 1e-3, 2.0, _capi.FLAG_ICP_RR_QUIRK | _capi.FLAG_HOST_LOOP)
+            except np.linalg.LinAlgError:
+                Th, ith = None, None
+            if Th is not None and (itd != ith or not np.array_equal(Td, Th)):
+                print("LOOP MISMATCH", n, kind, itd, ith); sys.exit(1)
     sc.close()
 print(f"soak ok: {passes} passes over {scans} scans in {time.time() - t0:.1f} s")
