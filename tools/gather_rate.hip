@@ -56,6 +56,41 @@ __global__ void __launch_bounds__(256, 5) k_gather_w(const float *__restrict__ a
     if (best == 123.456f) out[gid] = best;
 }
 
+// Address path: the same dependent walk with (0) 64-bit per-lane addresses (global_load, vaddr pair), (1) a
+// uniform base + 32-bit per-lane offset (global_load ... saddr), (2) buffer_load ... offen (descriptor + 32-bit offset).
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+template <int MODE>
+__global__ void __launch_bounds__(256, 5) k_gather_addr(const float4 *__restrict__ a, uint32_t nb, int iters, int group, float *out) {
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t stream = gid / group;
+    uint32_t idx = mix(stream) % nb;
+    float best = 1e30f;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a, 0, nb * 64u, 0x00027000);
+    for (int it = 0; it < iters; ++it) {
+        float4 p[4];
+        if (MODE == 0) {
+            const float4 *b = a + (size_t)idx * 4 + (size_t)(it & 0) * (1ull << 33);     // keeps the address 64-bit
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u] = b[u];
+        } else if (MODE == 1) {
+            const uint32_t off = idx * 64u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u] = *(const float4 *)((const char *)a + (off + 16u * u));
+        } else {
+            const uint32_t off = idx * 64u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const u4v v = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16u * u, 0, 0);
+                p[u] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) best = fminf(best, p[u].x * p[u].x + p[u].y);
+        idx = (mix(idx + stream * 2654435761u + it) + (__float_as_uint(p[0].w) & 1u)) % nb;
+    }
+    if (best == 123.456f) out[gid] = best;
+}
+
 int main() {
     const uint32_t n = 1u << 20;                     // 16 MiB of float4: L2 (4 MiB per XCD) misses, MALL hits
     std::vector<float> h((size_t)n * 4);
@@ -104,6 +139,24 @@ int main() {
             }
             const double cyc = ms * 1e-3 * ghz * 1e9;
             printf(" %8.1f", cyc / ((double)blocks * 4 * iters * 4 / cus));
+        }
+        printf("\n");
+    }
+    printf("\naddress path (dwordx4, dependent walk, all lanes active): cycles per wave-level load instruction per CU\n%6s %12s %12s %12s\n", "group", "global vaddr", "global saddr", "buffer offen");
+    for (int group : {1, 4, 8, 16, 64}) {
+        printf("%6d", group);
+        for (int m = 0; m < 3; ++m) {
+            float ms = 0;
+            for (int rep = 0; rep < 3; ++rep) {
+                CHECK(hipEventRecord(e0));
+                if (m == 0) hipLaunchKernelGGL(k_gather_addr<0>, dim3(blocks), dim3(256), 0, 0, d, n / 4, iters, group, o);
+                if (m == 1) hipLaunchKernelGGL(k_gather_addr<1>, dim3(blocks), dim3(256), 0, 0, d, n / 4, iters, group, o);
+                if (m == 2) hipLaunchKernelGGL(k_gather_addr<2>, dim3(blocks), dim3(256), 0, 0, d, n / 4, iters, group, o);
+                CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
+            }
+            const double cyc = ms * 1e-3 * ghz * 1e9;
+            printf(" %12.1f", cyc / ((double)blocks * 4 * iters * 4 / cus));
         }
         printf("\n");
     }
