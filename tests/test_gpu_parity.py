@@ -727,3 +727,20 @@ def test_fuzz_against_oracle(capi, orc, ctx, seed):
                 assert abs(e2 - e2o) <= 1e-9 * max(abs(e2o), 1e-300)
             else:
                 assert not np.any(out[:28])
+        # voxel kinds (statistics from the oracle, as in make_targets): nearest CENTROID in float64
+        vs = float(scale * rng.choice([0.2, 0.5, 1.0]))
+        o_vox = orc.TargetVoxels(target, vs)
+        if n_t >= 300 and o_vox.mean.shape[0] > 0:
+            g_vox = capi.Target.voxels_from_stats(ctx, o_vox.mean, o_vox.norm, o_vox.icov, vs)
+            dv, iv = g_vox.nn_query(st)
+            dvo, ivo = orc.nn_brute_f64(o_vox.mean, st)
+            assert np.array_equal(iv, ivo) and np.array_equal(dv, dvo)
+            for kind in (capi.VPLANE, capi.NDT):
+                out = capi.linearize(g_vox, sc, kind, T, max_dist)
+                H, g, e2, cnt = capi.unpack29(out)
+                Ho, go, e2o, cnto = orc.calc_H_g_e2(kind, o_vox, T, source, max_dist, with_count=True)
+                assert cnt == cnto, (name, kind, cnt, cnto)
+                if cnto:
+                    assert rel_H(H, Ho) < 1e-9, (name, kind, rel_H(H, Ho))
+                    assert np.max(np.abs(g - go)) <= 1e-9 * max(np.max(np.abs(H)), np.max(np.abs(go)), 1e-300), (name, kind)
+                    assert abs(e2 - e2o) <= 1e-9 * max(abs(e2o), 1e-300)
