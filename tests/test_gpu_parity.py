@@ -744,3 +744,25 @@ def test_fuzz_against_oracle(capi, orc, ctx, seed):
                     assert rel_H(H, Ho) < 1e-9, (name, kind, rel_H(H, Ho))
                     assert np.max(np.abs(g - go)) <= 1e-9 * max(np.max(np.abs(H)), np.max(np.abs(go)), 1e-300), (name, kind)
                     assert abs(e2 - e2o) <= 1e-9 * max(abs(e2o), 1e-300)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_voxel_build(capi, orc, ctx, seed):
+    """GPU voxel build (keys, counts, means, covariances, inverse covariances) against the oracle's restatement
+    of voxel.py:12-21,69-165 on random cloud families, scales, offsets, voxel sizes and input dtypes."""
+    rng = np.random.default_rng(2000 + seed)
+    n = int(rng.choice([30, 500, 5000, 40000]))
+    pts, scale = _fuzz_cloud(rng, n)
+    if rng.integers(0, 2):
+        pts = pts.astype(np.float64) + rng.normal(0, 1e-7 * scale, pts.shape)      # float64 input with digits float32 lacks
+    vs = float(scale * rng.choice([0.05, 0.2, 1.0, 3.0]))
+    min_points = int(rng.choice([1, 10, 10, 25]))
+    t = capi.Target.voxels(ctx, pts, vs, min_points)
+    o = orc.voxel_build(pts, vs, min_points)
+    assert t.size() == o["mean"].shape[0]
+    if t.size() == 0:
+        return
+    st = t.voxel_stats()
+    assert np.array_equal(st["keys"], o["keys"]) and np.array_equal(st["counts"], o["counts"])
+    assert np.array_equal(st["mean"], o["mean"]) and np.array_equal(st["cov"], o["cov"])
+    assert np.allclose(st["icov"], orc.calc_icov(o["cov"]), rtol=1e-13, atol=0)
