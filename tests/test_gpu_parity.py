@@ -766,3 +766,44 @@ def test_fuzz_voxel_build(capi, orc, ctx, seed):
     assert np.array_equal(st["keys"], o["keys"]) and np.array_equal(st["counts"], o["counts"])
     assert np.array_equal(st["mean"], o["mean"]) and np.array_equal(st["cov"], o["cov"])
     assert np.allclose(st["icov"], orc.calc_icov(o["cov"]), rtol=1e-13, atol=0)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_align_against_oracle_loop(capi, orc, ctx, seed):
+    """pcr_align (device-resident loop) against the reference's loop (registration.py:89-111) driven by the
+    ORACLE's calc_H_g_e2 on random LiDAR-like clouds: same number of iterations, same pose."""
+    from point_cloud_registration_amd.math_tools import makeT, expSO3, plus
+    from point_cloud_registration_amd.synthetic import street
+    rng = np.random.default_rng(3000 + seed)
+    target = street(int(rng.choice([20_000, 60_000])), seed=100 + seed)
+    target = (target * float(rng.choice([1.0, 0.3, 3.0])) + rng.uniform(-50, 50, 3)).astype(np.float32)
+    extent = float(np.max(target.max(0) - target.min(0)))
+    T_true = makeT(expSO3(rng.normal(0, 0.01, 3)), rng.normal(0, 0.002 * extent, 3))
+    idx = rng.choice(target.shape[0], 5000, replace=False)
+    Ri, ti = T_true[:3, :3].T, -T_true[:3, :3].T @ T_true[:3, 3]
+    source = ((Ri @ target[idx].astype(np.float64).T).T + ti + rng.normal(0, 1e-4 * extent, (5000, 3))).astype(np.float32)
+    max_dist = 0.05 * extent
+    normals = rng.normal(size=target.shape).astype(np.float32)
+    normals /= np.linalg.norm(normals, axis=1, keepdims=True)
+    vs = 0.02 * extent
+    gt, ot = make_targets(capi, orc, ctx, target, normals, vs)
+    name = NAMES[seed % 4]
+    kind = kind_of(capi, name)
+    max_iter, tol = 25, 1e-3
+    T = np.eye(4)
+    iters = 0
+    margin = np.inf                                    # how close any |dx| came to the tolerance
+    for it in range(max_iter):
+        H, g, e2 = orc.calc_H_g_e2(kind, ot[name], T, source, max_dist)
+        dx = -np.linalg.solve(H, g)
+        iters = it + 1
+        margin = min(margin, abs(np.linalg.norm(dx) - tol))
+        if np.linalg.norm(dx) < tol:
+            break
+        T = plus(T, dx)
+    assert iters >= 2                                  # the pose really had to move
+    sc = capi.Scan(ctx, source)
+    Tg, itg = capi.align(gt[name], sc, kind, np.eye(4), max_iter, tol, max_dist)
+    if margin > 1e-6:                                  # a step that lands ON the tolerance may fall either way
+        assert itg == iters, (name, itg, iters)
+        assert np.max(np.abs(Tg - T)) < 1e-7 * max(extent, 1.0), (name, np.max(np.abs(Tg - T)))
