@@ -807,3 +807,22 @@ def test_fuzz_align_against_oracle_loop(capi, orc, ctx, seed):
     if margin > 1e-6:                                  # a step that lands ON the tolerance may fall either way
         assert itg == iters, (name, itg, iters)
         assert np.max(np.abs(Tg - T)) < 1e-7 * max(extent, 1.0), (name, np.max(np.abs(Tg - T)))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_knn(capi, orc, ctx, seed):
+    """Exact k-NN (estimate_normals.py:27-45's tree query) on random cloud families / scales / offsets, k from 1
+    to 20, clouds with fewer points than k included: distances AND indices bit-exact against brute force (ties
+    in distance are ordered by the smaller index on both sides)."""
+    rng = np.random.default_rng(4000 + seed)
+    n = int(rng.choice([3, 40, 700, 6000]))
+    pts, scale = _fuzz_cloud(rng, n)
+    n = pts.shape[0]
+    k = int(rng.choice([1, 2, 5, 15, 20]))
+    q = np.vstack([pts[rng.integers(0, n, 200)], (pts[rng.integers(0, n, 100)].astype(np.float64)
+                                                  + rng.normal(0, 0.05 * scale, (100, 3))).astype(np.float32)])
+    t = capi.Target.points(ctx, pts)
+    d, i = t.knn_query(q, k)
+    do, io = orc.knn_brute(pts, q, k)
+    assert np.array_equal(d, do)
+    assert np.array_equal(i, io)
