@@ -58,7 +58,17 @@ CONFIGS = {
     "ndt_10m": ("ndt", 10_000_000, 10_000_000, 1.0, "NDT voxel_size=1.0, synthetic 10M-pt cloud"),
     "plane_100m": ("plane", 100_000_000, 12_500_000, None,
                    "Point-to-Plane ICP, synthetic 100M-pt target, 12.5M scan points per GPU"),
+    # scans that are NOT copies of target points: the same surfaces sampled independently (what a real
+    # sweep is: matches sit at ~half the point spacing instead of at the noise level), and a 30 %-overlap crop
+    "plane_b01_resampled": ("plane", 1_060_000, 1_060_000, None,
+                            "Point-to-Plane ICP, B-01 stand-in vs an INDEPENDENT sample of the same surfaces (street seed != 0)"),
+    "plane_b01_crop": ("plane", 1_060_000, 1_060_000, None,
+                       "Point-to-Plane ICP, B-01 stand-in vs an independent sample of the street and of the next block, "
+                       "cropped to x in [24, 144] m: 30 % of the scan overlaps the map"),
+    "plane_100m_resampled": ("plane", 100_000_000, 12_500_000, None,
+                             "Point-to-Plane ICP, synthetic 100M-pt target vs an independent 12.5M-pt sample of the same surfaces"),
 }
+SCAN_FAMILY = {"plane_b01_resampled": "resampled", "plane_b01_crop": "crop", "plane_100m_resampled": "resampled"}
 
 
 def parse():
@@ -110,6 +120,40 @@ def kernel_source_hash():
 def make_cloud(n, seed):
     from point_cloud_registration_amd.synthetic import street, street_tiled
     return street(n, seed=seed) if n <= 2_000_000 else street_tiled(n, seed=seed)
+
+
+def make_scan(config, target, n_scan, family=None, seed=2):
+    """The scan of a config and the pose align() should recover.  Families: "copy" (SURVEY.md 8d / the reference
+    harness: a noisy copy of target points), "resampled" (an independent sample of the same surfaces, moved by
+    T_true^-1, same noise), "crop" (the same, over a region of which only 30 % lies inside the map)."""
+    from point_cloud_registration_amd.synthetic import (harness_scan, perturbed_scan, street, street_tiled, make_T,
+                                                        T_TRUE_SO3, T_TRUE_T)
+    family = family or SCAN_FAMILY.get(config, "copy")
+    n_target = target.shape[0]
+    if "harness" in config:
+        T_true = np.eye(4)
+        T_true[2, 3] = -0.3                                   # align(scan, I) undoes the +0.3 m shift
+        return harness_scan(target, n_scan, seed=seed - 1), T_true
+    if family == "copy":
+        return perturbed_scan(target, n_scan if n_scan < n_target else None, seed=seed)
+    if family == "crop":
+        # the map's street and the next block (its own walls at x = 60 and 180), seen from a sensor that covers
+        # x in [24, 144]: 36 m of the map (with its x = 60 wall, which pins the solution along the street) + 84 m beyond
+        two = np.concatenate([street(2 * n_scan, seed=1000 + seed), street(2 * n_scan, seed=2000 + seed, center=(120.0, 0.0))])
+        two = two[(two[:, 0] > 24.0) & (two[:, 0] < 144.0)]
+        world = two[np.random.default_rng(seed).permutation(two.shape[0])[:n_scan]]
+    elif n_target <= 2_000_000:
+        world = street(n_scan, seed=1000 + seed)
+    else:
+        world = street_tiled(n_scan, seed=1000 + seed, per_tile=max(n_scan // max(round(n_target / 1_000_000), 1), 1))
+    T_true = make_T(T_TRUE_SO3, T_TRUE_T)
+    Ri = T_true[:3, :3].T
+    rng = np.random.default_rng(seed)
+    out = np.empty_like(world)
+    for lo in range(0, world.shape[0], 4_000_000):            # chunked: the 12.5 M-point case in float64
+        w = world[lo:lo + 4_000_000].astype(np.float64)
+        out[lo:lo + 4_000_000] = ((w - T_true[:3, 3]) @ Ri.T + rng.normal(0.0, 0.005, w.shape)).astype(np.float32)
+    return out, T_true
 
 
 def main():
@@ -165,12 +209,7 @@ def main():
         target = make_cloud(n_target, seed=0)
     strong = args.scaling == "strong"
     sseed = 0 if strong else rank                              # strong: every rank builds the SAME scan, keeps a shard
-    if "harness" in args.config:
-        scan = harness_scan(target, n_scan, seed=1 + sseed)
-        T_true = np.eye(4)
-        T_true[2, 3] = -0.3                                   # align(scan, I) undoes the +0.3 m shift
-    else:
-        scan, T_true = perturbed_scan(target, n_scan if n_scan < n_target else None, seed=2 + sseed)
+    scan, T_true = make_scan(args.config, target, n_scan, seed=2 + sseed)
     n_scan_job = scan.shape[0] if strong else scan.shape[0] * world
     if strong:
         scan = np.ascontiguousarray(pdist.shard_scan(scan, rank, world))

@@ -170,7 +170,7 @@ PCR_API pcr_status pcr_knn_query(pcr_target *t, const float *q, int64_t m, int k
  * launch count and total milliseconds since the last reset.  on = n > 1 brackets only every
  * n-th pass (an event pair costs a few microseconds of stream time: sampling keeps a timed
  * region honest); on = 1 every pass; 0 off.                                                 */
-enum { PCR_K_LINEARIZE = 0, PCR_K_FINALIZE = 1, PCR_K_NN = 2, PCR_K_REDUCE = 3, PCR_K_ALLREDUCE = 4, PCR_K_COUNT = 5 };
+enum { PCR_K_LINEARIZE = 0, PCR_K_FINALIZE = 1, PCR_K_NN = 2, PCR_K_REDUCE = 3, PCR_K_ALLREDUCE = 4, PCR_K_CERTIFY = 5, PCR_K_COUNT = 6 };
 PCR_API pcr_status pcr_profile_enable(pcr_context *ctx, int on);
 PCR_API pcr_status pcr_profile_reset(pcr_context *ctx);
 PCR_API pcr_status pcr_profile_read(pcr_context *ctx, int64_t launches[PCR_K_COUNT], double total_ms[PCR_K_COUNT]);
@@ -191,9 +191,22 @@ PCR_API pcr_status pcr_nn_counters(pcr_target *t, pcr_scan *s, const double T[16
  * points 49 vs 59 us per pass); either way the last blocks fold the partial sums inside the kernel   */
 PCR_API pcr_status pcr_set_variant(pcr_context *ctx, int variant);
 PCR_API pcr_status pcr_get_variant(pcr_context *ctx, int *variant);
-/* NN search mode of variant 1: 0 = plain ring search, 1 = start every search from the scan
- * point's match of the previous pass against the same target (an exact upper bound)       */
+/* NN search kernel of variant 1: 0 = per-lane ring search (shipped), 2 = wave-cooperative LDS-staged search */
 PCR_API pcr_status pcr_set_nn_mode(pcr_context *ctx, int mode);
+/* Certified reuse of the previous pass' matches (no reference counterpart: Registration.align,
+ * registration.py:89-111, searches afresh every iteration).  When consecutive passes over one scan and target
+ * differ by a small pose change, a pass first proves -- per point, by the triangle inequality on a bound the
+ * previous search recorded -- that the old match is still the exact nearest neighbour, and searches only the
+ * points where the proof fails.  The correspondences, and therefore all 29 sums, are bit-identical to a full
+ * search; only the time changes.  mode: 0 = off, 1 = automatic (default: tried when the scan's typical
+ * displacement since the last pass is below tau x cell size of the target's index), 2 = always.  mu = how far
+ * beyond its match a tracking search looks, x cell size.  tau / mu <= 0 keep the current value.          */
+PCR_API pcr_status pcr_set_reuse(pcr_context *ctx, int mode, double tau, double mu);
+PCR_API pcr_status pcr_get_reuse(pcr_context *ctx, int *mode, double *tau, double *mu);
+/* out[0..2] = passes over this scan by search mode (full, tracking, certify + list); out[3] / out[4] = points
+ * the list passes had to search / points they covered; out[5..7] = mode, searched points (-1 = not read
+ * back) and typical displacement (m) of the last pass                                                      */
+PCR_API pcr_status pcr_scan_reuse_stats(pcr_scan *s, double out[8]);
 /* variant 1: 1 (default) = the reduce kernel folds the per-block partial sums itself
  * (k_reduce_finalize); 0 = separate fold kernel                                             */
 PCR_API pcr_status pcr_set_fuse_finalize(pcr_context *ctx, int on);

@@ -22,8 +22,9 @@ FLAG_ICP_RR_QUIRK = 1
 FLAG_NO_SCAN_SORT = 2
 FLAG_LOCAL_ONLY = 4          # no all-reduce even when the context has a communicator
 FLAG_HOST_LOOP = 8           # pcr_align: host-driven loop instead of the device-resident one
-K_LINEARIZE, K_FINALIZE, K_NN, K_REDUCE, K_ALLREDUCE, K_COUNT = 0, 1, 2, 3, 4, 5
-KERNEL_NAMES = ("linearize", "finalize", "nn", "reduce", "allreduce")
+K_LINEARIZE, K_FINALIZE, K_NN, K_REDUCE, K_ALLREDUCE, K_CERTIFY, K_COUNT = 0, 1, 2, 3, 4, 5, 6
+KERNEL_NAMES = ("linearize", "finalize", "nn", "reduce", "allreduce", "certify")
+NN_FULL, NN_TRACK, NN_LIST = 0, 1, 2      # what the search of a pass did (certified reuse, include/pcr.h)
 
 _lib = None
 _torch_lib_dir = None           # set when torch's bundled HIP runtime was pre-loaded (see below)
@@ -78,6 +79,9 @@ PROTOTYPES = {
     "pcr_set_fuse_finalize": (C.c_int, [_vp, C.c_int]),
     "pcr_get_pipeline": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pcr_nn_counters": (C.c_int, [_vp, _vp, _f64p, C.c_double, _f64p]),
+    "pcr_set_reuse": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double]),
+    "pcr_get_reuse": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "pcr_scan_reuse_stats": (C.c_int, [_vp, _f64p]),
 }
 
 
@@ -201,12 +205,24 @@ class Context:
     def set_fuse_finalize(self, on):
         check(lib().pcr_set_fuse_finalize(self.handle, int(bool(on))))
 
+    def set_reuse(self, mode=None, tau=0.0, mu=0.0):
+        """Certified reuse of the previous pass' matches: 0 off, 1 automatic (default), 2 always; ``tau`` / ``mu``
+        in units of the target index' cell size (<= 0 keeps the current value)."""
+        if mode is None:
+            mode = self.get_reuse()["mode"]
+        check(lib().pcr_set_reuse(self.handle, int(mode), float(tau), float(mu)))
+
+    def get_reuse(self):
+        m, t, u = C.c_int(0), C.c_double(0), C.c_double(0)
+        check(lib().pcr_get_reuse(self.handle, C.byref(m), C.byref(t), C.byref(u)))
+        return {"mode": m.value, "tau": t.value, "mu": u.value}
+
     def get_pipeline(self):
         v, f, m = C.c_int(0), C.c_int(0), C.c_int(0)
         check(lib().pcr_get_pipeline(self.handle, C.byref(v), C.byref(f), C.byref(m)))
-        return {"variant": v.value, "fuse_finalize": f.value, "nn_mode": m.value}
+        return {"variant": v.value, "fuse_finalize": f.value, "nn_mode": m.value, "reuse": self.get_reuse()["mode"]}
 
-    def pipeline(self, variant=None, fuse_finalize=None, nn_mode=None):
+    def pipeline(self, variant=None, fuse_finalize=None, nn_mode=None, reuse=None):
         """Context manager: select a kernel pipeline for the enclosed calls and RESTORE the previous
         selection afterwards (the context is process-wide)."""
         import contextlib
@@ -221,11 +237,14 @@ class Context:
                     self.set_fuse_finalize(fuse_finalize)
                 if nn_mode is not None:
                     self.set_nn_mode(nn_mode)
+                if reuse is not None:
+                    self.set_reuse(reuse)
                 yield self
             finally:
                 self.set_variant(prev["variant"])
                 self.set_fuse_finalize(prev["fuse_finalize"])
                 self.set_nn_mode(prev["nn_mode"])
+                self.set_reuse(prev["reuse"])
         return _cm()
 
     # -- RCCL
@@ -436,6 +455,14 @@ class Scan:
             self.n = xyz.shape[0]
         self.handle = h
         _live.add(self)
+
+    def reuse_stats(self):
+        """Certified reuse on this scan: passes by search mode, points the list passes searched, last pass."""
+        o = np.zeros(8)
+        check(lib().pcr_scan_reuse_stats(self.handle, o))
+        return {"passes_full": int(o[0]), "passes_track": int(o[1]), "passes_list": int(o[2]),
+                "list_searched": int(o[3]), "list_points": int(o[4]),
+                "last_mode": int(o[5]), "last_searched": int(o[6]), "last_motion": float(o[7])}
 
     def close(self):
         if getattr(self, "handle", None) and not _shutdown:

@@ -101,6 +101,14 @@ extern "C" pcr_status pcr_context_create(int device, pcr_context **out) {
     if (nm && *nm) ctx->nn_mode = atoi(nm);
     const char *ff = getenv("PCR_FUSE_FINALIZE");
     if (ff && *ff) ctx->fuse_finalize = atoi(ff) != 0;
+    const char *tl = getenv("PCR_TILE_LOCAL");
+    if (tl && *tl) ctx->tile_local = atoi(tl) != 0;
+    const char *ru = getenv("PCR_REUSE");
+    if (ru && *ru) ctx->reuse = atoi(ru);
+    const char *rt = getenv("PCR_REUSE_TAU");
+    if (rt && *rt) ctx->reuse_tau = atof(rt);
+    const char *rm = getenv("PCR_REUSE_MU");
+    if (rm && *rm) ctx->reuse_mu = atof(rm);
     *out = ctx;
     return PCR_OK;
 }
@@ -165,8 +173,33 @@ extern "C" pcr_status pcr_get_pipeline(pcr_context *ctx, int *variant, int *fuse
 
 extern "C" pcr_status pcr_set_nn_mode(pcr_context *ctx, int mode) {
     PCR_REQUIRE(ctx, "ctx is NULL");
-    PCR_REQUIRE(mode >= 0 && mode <= 2, "nn mode must be 0, 1 or 2");
+    PCR_REQUIRE(mode == 0 || mode == 2, "nn mode must be 0 or 2");
     ctx->nn_mode = mode;
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_set_reuse(pcr_context *ctx, int mode, double tau, double mu) {
+    PCR_REQUIRE(ctx, "ctx is NULL");
+    PCR_REQUIRE(mode >= 0 && mode <= 2, "reuse mode must be 0 (off), 1 (automatic) or 2 (forced)");
+    ctx->reuse = mode;
+    if (tau > 0) ctx->reuse_tau = tau;
+    if (mu > 0) ctx->reuse_mu = mu;
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_get_reuse(pcr_context *ctx, int *mode, double *tau, double *mu) {
+    PCR_REQUIRE(ctx, "ctx is NULL");
+    if (mode) *mode = ctx->reuse;
+    if (tau) *tau = ctx->reuse_tau;
+    if (mu) *mu = ctx->reuse_mu;
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_scan_reuse_stats(pcr_scan *s, double out[8]) {
+    PCR_REQUIRE(s && out, "NULL argument");
+    out[0] = (double)s->st_passes[0]; out[1] = (double)s->st_passes[1]; out[2] = (double)s->st_passes[2];
+    out[3] = (double)s->st_marked; out[4] = (double)s->st_listed_of;
+    out[5] = (double)s->last_mode; out[6] = (double)s->last_marked; out[7] = s->last_motion;
     return PCR_OK;
 }
 
@@ -486,6 +519,9 @@ extern "C" pcr_status pcr_scan_destroy(pcr_scan *s) {
     if (s->y) (void)hipFree(s->y);
     if (s->z) (void)hipFree(s->z);
     if (s->nn_j) (void)hipFree(s->nn_j);
+    if (s->lb2) (void)hipFree(s->lb2);
+    if (s->umask) (void)hipFree(s->umask);
+    if (s->ucnt) (void)hipFree(s->ucnt);
     delete s;
     return PCR_OK;
 }
@@ -532,7 +568,8 @@ extern "C" pcr_status pcr_align(pcr_target *t, pcr_scan *s, int kind, const doub
                                 double max_dist, unsigned flags, double T_out[16], int *iterations,
                                 double *trace_or_null) {
     PCR_REQUIRE(t && s && T_init && T_out, "NULL argument");
-    if (flags & PCR_FLAG_HOST_LOOP)
+    // (certified reuse runs on host-driven passes; forced on, the loop is driven from the host)
+    if ((flags & PCR_FLAG_HOST_LOOP) || t->ctx->reuse == 2)
         return align_host_loop(t, s, kind, T_init, max_iter, tol, max_dist, flags, T_out, iterations, trace_or_null);
     return pcr_run_align(t, s, kind, T_init, max_iter, tol, max_dist, flags, T_out, iterations, trace_or_null);
 }

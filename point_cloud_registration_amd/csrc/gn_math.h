@@ -109,3 +109,41 @@ PCR_HD static inline int gn_step(double (*A)[7], const double o[29], double tol,
     gn_se3_plus(T, dx);
     return 0;
 }
+
+// ---- certified reuse: when is it worth trying? -------------------------------------------------------
+// Typical displacement of a scan between two poses: mean over the centre and the six face centres of its
+// bounding box (centre c, half extents e) of |Tb p - Ta p|.  The same code decides on the host
+// (pcr_linearize) and on the device (k_gn_update), so both loops take the same decisions -- which only
+// affect speed: the certificate itself is exact, a pass returns the same bits whatever was decided.
+PCR_HD static inline double gn_typical_motion(const double Ta[16], const double Tb[16], const float c[3], const float e[3]) {
+    double sum = 0;
+    for (int k = 0; k < 7; ++k) {
+        double p[3] = {(double)c[0], (double)c[1], (double)c[2]};
+        if (k > 0) { const int ax = (k - 1) >> 1; p[ax] += ((k - 1) & 1) ? (double)e[ax] : -(double)e[ax]; }
+        double d2 = 0;
+        for (int i = 0; i < 3; ++i) {
+            const double a = Ta[4 * i] * p[0] + Ta[4 * i + 1] * p[1] + Ta[4 * i + 2] * p[2] + Ta[4 * i + 3];
+            const double b = Tb[4 * i] * p[0] + Tb[4 * i + 1] * p[1] + Tb[4 * i + 2] * p[2] + Tb[4 * i + 3];
+            d2 += (b - a) * (b - a);
+        }
+        sum += sqrt(d2);
+    }
+    return sum / 7.0;
+}
+
+// 0 = plain search, 1 = tracking search (leaves certifiable matches behind), 2 = certify the previous matches and
+// search only the rest (PCR_NN_FULL / TRACK / LIST in pcr_internal.h).  reuse: 0 off, 1 automatic, 2 forced.
+// Automatic: nothing while the scan still moves by more than tau_len per pass.  Below that, keep going once
+// tracking; START tracking (a tracking pass costs 10-40 % more than a plain one and pays only if further passes
+// follow) when the pose is being re-evaluated in place (motion 0) or converges slowly (this step more than 0.3 of
+// the previous one: with the quadratic convergence of a well-conditioned Gauss-Newton run the loop ends first).
+PCR_HD static inline int gn_choose_nn_mode(int reuse, int have_prev, int track_valid, double motion, double prev_motion,
+                                           double tau_len) {
+    if (reuse == 0 || !have_prev) return 0;
+    if (reuse == 2) return track_valid ? 2 : 1;
+    if (!(motion < tau_len)) return 0;
+    if (track_valid) return 2;
+    if (motion == 0.0) return 1;
+    if (prev_motion >= 0.0 && prev_motion < 8.0 * tau_len && motion > 0.3 * prev_motion) return 1;
+    return 0;
+}

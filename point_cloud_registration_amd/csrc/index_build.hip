@@ -615,14 +615,18 @@ pcr_status pcr_sort_scan(pcr_context *ctx, const float *d_xyz, int64_t n, unsign
     s->n = n;
     if (n == 0) return PCR_OK;
     const unsigned nb = (unsigned)((n + 255) / 256);
+    float lo[3], hi[3];
+    PCR_TRY(device_bbox<float>(ctx, d_xyz, n, lo, hi));
+    for (int i = 0; i < 3; ++i) {          // (certified reuse: where the scan is, to judge how far a pose change moves it)
+        s->bb_c[i] = 0.5f * (lo[i] + hi[i]); s->bb_e[i] = 0.5f * (hi[i] - lo[i]);
+        if (!(fabsf(s->bb_c[i]) < 1e30f) || !(s->bb_e[i] < 1e30f)) { s->bb_c[i] = 0.f; s->bb_e[i] = 1e30f; }
+    }
     if (flags & PCR_FLAG_NO_SCAN_SORT) {
         hipLaunchKernelGGL(k_to_soa, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, (const uint32_t *)nullptr, n, s->x, s->y, s->z);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         return PCR_OK;
     }
-    float lo[3], hi[3];
-    PCR_TRY(device_bbox<float>(ctx, d_xyz, n, lo, hi));
     float ext = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
     if (!(ext > 0)) ext = 1.f;
     const float scale = 2097151.f / ext;

@@ -35,6 +35,10 @@ struct PoseK {
     float r32[9], t32[3];
     double R[9];
 };
+// the transform half of a pose only (the previous pass' pose)
+struct PoseQ {
+    float r32[9], t32[3];
+};
 
 struct LinArgs {
     // scan
@@ -54,6 +58,12 @@ struct LinArgs {
     // start (pcr_align: the device-resident Gauss-Newton loop; pose->done != 0 turns the launch into a no-op)
     PoseK hp;
     const PoseDev *pose;
+    // certified reuse: the float32 pose of the previous pass over this scan (k_certify, tracking searches)
+    PoseQ hq;
+    float *lb2;                      // per scan point: lower bound on the distance to every target point but its match
+    unsigned long long *umask;       // per 64-point tile: lanes k_certify could not certify
+    uint32_t *ucnt;                  // per k_certify block: points marked
+    float mu_f;                      // margin of a tracking search (metres); also the per-point motion gate
     float md_f;        // gate, float32 compare (point targets)
     double md_d;       // gate, float64 compare (voxel targets)
     float bound2_f;    // search bound (squared), slightly above the gate
@@ -92,7 +102,11 @@ __device__ __forceinline__ bool load_pose(const LinArgs &a, PoseK &P) {
     return true;
 }
 
-__device__ __forceinline__ void xform(const PoseK &a, float x, float y, float z, float &tx, float &ty, float &tz) {
+// the previous pass' float32 pose (certified reuse runs on host-driven passes only: by value)
+__device__ __forceinline__ void load_prev(const LinArgs &a, PoseQ &Q) { Q = a.hq; }
+
+template <typename POSE>
+__device__ __forceinline__ void xform(const POSE &a, float x, float y, float z, float &tx, float &ty, float &tz) {
     // ((R00*x + R01*y) + R02*z) + t0, float32, no contraction: oracle orc_transform
     tx = ((a.r32[0] * x + a.r32[1] * y) + a.r32[2] * z) + a.t32[0];
     ty = ((a.r32[3] * x + a.r32[4] * y) + a.r32[5] * z) + a.t32[1];
@@ -179,25 +193,43 @@ __device__ __forceinline__ void acc_ndt(double *acc, const PoseK &a, double x, d
     acc[28] += 1.0;
 }
 
-// gather the matched record at cell-sorted index j and accumulate
-template <int KIND>
+// the gate of the reference (icp.py:34, plane_icp.py:41, voxelized_plane_icp.py:38, ndt.py:33: dist < max_dist, strict), on
+// the distance exactly as the search computes it (nn_test): the reduce kernels apply it themselves, so that the
+// search may leave UNGATED matches behind for the next pass (certified reuse)
+__device__ __forceinline__ bool gate_f32(const LinArgs &a, float dx, float dy, float dz) {
+    return __builtin_sqrtf(dist2_f32(dx, dy, dz)) < a.md_f;
+}
+__device__ __forceinline__ bool gate_f64(const LinArgs &a, double dx, double dy, double dz) {
+    return __builtin_sqrt((dx * dx + dy * dy) + dz * dz) < a.md_d;
+}
+
+// gather the matched record at cell-sorted index j and accumulate (GATE: apply the distance gate here)
+template <int KIND, bool GATE>
 __device__ __forceinline__ void accumulate(double *acc, const LinArgs &a, const PoseK &P, uint32_t j,
                                            float x, float y, float z, float tx, float ty, float tz) {
     if (KIND == PCR_ICP) {
         const PtF q = a.pts[j];
-        acc_icp(acc, P, a.flags, x, y, z, (double)(tx - q.x), (double)(ty - q.y), (double)(tz - q.z));   // icp.py:39
+        const float dx = tx - q.x, dy = ty - q.y, dz = tz - q.z;
+        if (GATE && !gate_f32(a, dx, dy, dz)) return;
+        acc_icp(acc, P, a.flags, x, y, z, (double)dx, (double)dy, (double)dz);   // icp.py:39
     } else if (KIND == PCR_PLANE) {
         // point and normal from ONE 32-byte record (two 16-byte loads of the same sector)
         const float4 *rec = reinterpret_cast<const float4 *>(a.pn + j);
         const float4 q = rec[0], nn = rec[1];
-        acc_plane(acc, P, x, y, z, nn.x, nn.y, nn.z, (double)(tx - q.x), (double)(ty - q.y), (double)(tz - q.z));
+        const float dx = tx - q.x, dy = ty - q.y, dz = tz - q.z;
+        if (GATE && !gate_f32(a, dx, dy, dz)) return;
+        acc_plane(acc, P, x, y, z, nn.x, nn.y, nn.z, (double)dx, (double)dy, (double)dz);
     } else if (KIND == PCR_VPLANE) {
         const PtD q = a.means[j];
+        const double dx = (double)tx - q.x, dy = (double)ty - q.y, dz = (double)tz - q.z;
+        if (GATE && !gate_f64(a, dx, dy, dz)) return;
         const double *nn = a.vnorm + 3 * (size_t)j;
-        acc_plane(acc, P, x, y, z, nn[0], nn[1], nn[2], (double)tx - q.x, (double)ty - q.y, (double)tz - q.z);
+        acc_plane(acc, P, x, y, z, nn[0], nn[1], nn[2], dx, dy, dz);
     } else {
         const PtD q = a.means[j];
-        acc_ndt(acc, P, x, y, z, a.vicov + 6 * (size_t)j, (double)tx - q.x, (double)ty - q.y, (double)tz - q.z);
+        const double dx = (double)tx - q.x, dy = (double)ty - q.y, dz = (double)tz - q.z;
+        if (GATE && !gate_f64(a, dx, dy, dz)) return;
+        acc_ndt(acc, P, x, y, z, a.vicov + 6 * (size_t)j, dx, dy, dz);
     }
 }
 
@@ -227,15 +259,21 @@ __device__ __forceinline__ void reduce_stream(double *acc, const LinArgs &a, con
                 const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
                 float tx, ty, tz;
                 xform(P, x, y, z, tx, ty, tz);
-                if (KIND == PCR_PLANE) acc_plane(acc, P, x, y, z, n0.x, n0.y, n0.z, (double)(tx - q0.x), (double)(ty - q0.y), (double)(tz - q0.z));
-                else acc_icp(acc, P, a.flags, x, y, z, (double)(tx - q0.x), (double)(ty - q0.y), (double)(tz - q0.z));
+                const float dx = tx - q0.x, dy = ty - q0.y, dz = tz - q0.z;
+                if (gate_f32(a, dx, dy, dz)) {
+                    if (KIND == PCR_PLANE) acc_plane(acc, P, x, y, z, n0.x, n0.y, n0.z, (double)dx, (double)dy, (double)dz);
+                    else acc_icp(acc, P, a.flags, x, y, z, (double)dx, (double)dy, (double)dz);
+                }
             }
             if (ok1) {
                 const float x = a.sx[i1], y = a.sy[i1], z = a.sz[i1];
                 float tx, ty, tz;
                 xform(P, x, y, z, tx, ty, tz);
-                if (KIND == PCR_PLANE) acc_plane(acc, P, x, y, z, n1.x, n1.y, n1.z, (double)(tx - q1.x), (double)(ty - q1.y), (double)(tz - q1.z));
-                else acc_icp(acc, P, a.flags, x, y, z, (double)(tx - q1.x), (double)(ty - q1.y), (double)(tz - q1.z));
+                const float dx = tx - q1.x, dy = ty - q1.y, dz = tz - q1.z;
+                if (gate_f32(a, dx, dy, dz)) {
+                    if (KIND == PCR_PLANE) acc_plane(acc, P, x, y, z, n1.x, n1.y, n1.z, (double)dx, (double)dy, (double)dz);
+                    else acc_icp(acc, P, a.flags, x, y, z, (double)dx, (double)dy, (double)dz);
+                }
             }
         }
     } else {
@@ -245,7 +283,7 @@ __device__ __forceinline__ void reduce_stream(double *acc, const LinArgs &a, con
             const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
             float tx, ty, tz;
             xform(P, x, y, z, tx, ty, tz);
-            accumulate<KIND>(acc, a, P, j, x, y, z, tx, ty, tz);
+            accumulate<KIND, true>(acc, a, P, j, x, y, z, tx, ty, tz);
         }
     }
 }
@@ -339,7 +377,7 @@ __device__ __forceinline__ void linearize_body(const LinArgs &a, const PoseK &P,
             nn_search<double, PtD>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz, a.bound2_d, best, bj, bo);
             ok = bj != PCR_NONE && __builtin_sqrt(best) < a.md_d;                 // voxelized_plane_icp.py:38
         }
-        if (ok) accumulate<KIND>(acc, a, P, bj, x, y, z, tx, ty, tz);
+        if (ok) accumulate<KIND, false>(acc, a, P, bj, x, y, z, tx, ty, tz);
     }
 }
 
@@ -356,19 +394,9 @@ __global__ void __launch_bounds__(256) k_linearize(const LinArgs a) {
 
 // ---- variant 1: NN kernel (few registers, high occupancy) + streaming reduce kernel ---------
 // The cost of a query varies by more than 10x with its distance to the surface, so waves pull
-// 64-point tiles from a per-XCD counter instead of owning a fixed share: every wave stays busy
-// until its XCD's span of the scan is exhausted (the finalize step re-zeroes the counters).
-// SEED: the match of the PREVIOUS pass over this scan against this target (still in nn_j) starts
-// the search: any real target point is an exact upper bound, so only cells inside that radius are
-// looked at (the result is the same exact nearest neighbour).
-// developer ablations for timing studies (results are WRONG when set; never in a shipped build):
-//   PCR_NN_ABLATE 1 = no search at all, 2 = own cell only;  PCR_NN_STATIC 1 = round-robin tiles, no counters
-#ifndef PCR_NN_ABLATE
-#define PCR_NN_ABLATE 0
-#endif
-#ifndef PCR_NN_STATIC
-#define PCR_NN_STATIC 0
-#endif
+// tiles from counters instead of owning a fixed share: every wave stays busy until its XCD's span of
+// the scan is exhausted (the finalize step re-zeroes the counters).
+//
 // Tile hand-out.  The sorted scan is cut into PCR_TILE_CTRS contiguous sub-spans; sub-spans c, c + 8,
 // c + 16, ... belong to XCD c & 7 (blocks b with b % 8 == c run there: a locality assumption only).
 // A wave's first PCR_TILE_STATIC_ROUNDS tiles of its home sub-span are fixed by its index (no atomic:
@@ -385,8 +413,8 @@ __global__ void __launch_bounds__(256) k_linearize(const LinArgs a) {
 #define PCR_TILE_STATIC_ROUNDS 1   // 2 static rounds already unbalance the far poses (whole kernel 127 -> 155 us)
 #endif
 #define PCR_TILE_SUB (PCR_TILE_CTRS / 8)
-// calls body(first, end) wave-uniformly for every 64-point tile this wave is given: lane l owns scan
-// point first + l, which exists iff first + l < end
+// calls body(first, end) wave-uniformly for every TP-point tile this wave is given (TP = 64: lane l owns scan
+// point first + l, which exists iff first + l < end; TP = 1024: a chunk of a LIST pass, see nn_chunk_list)
 // Two hand-out policies, chosen per launch (LinArgs::sched_local):
 //  * block-local (mid-size scans: at most ~1.5 tiles per launched wave, i.e. up to ~590 k points; below
 //    ~262 k the fused kernel runs instead): the XCD's span is dealt round-robin to the XCD's blocks (block
@@ -396,7 +424,7 @@ __global__ void __launch_bounds__(256) k_linearize(const LinArgs a) {
 //  * global counters (everything larger): PCR_TILE_CTRS sub-spans, one static round, then device-wide
 //    counters.  With many tiles per wave and costs that differ 10x between regions the static deal
 //    loses more than the atomics cost (1.06 M: 134 vs 147 us; 1e8-point target: 3.3 vs 4.9 ms).
-template <int LOCAL, typename Body>
+template <int LOCAL, int TP, typename Body>
 __device__ __forceinline__ void nn_tile_loop(const LinArgs &a, Body &&body) {
     const int xcd = (int)(blockIdx.x & 7);
     const int lane = threadIdx.x & 63;
@@ -407,13 +435,13 @@ __device__ __forceinline__ void nn_tile_loop(const LinArgs &a, Body &&body) {
         __syncthreads();
     }
     // global-counter state
-    const int64_t gspan = (((a.n + PCR_TILE_CTRS - 1) / PCR_TILE_CTRS) + 63) & ~(int64_t)63;
+    const int64_t gspan = (((a.n + PCR_TILE_CTRS - 1) / PCR_TILE_CTRS) + (TP - 1)) & ~(int64_t)(TP - 1);
     const int home = (int)(xb % PCR_TILE_SUB);
     const uint32_t wrank = (xb / PCR_TILE_SUB) * 4 + (threadIdx.x >> 6);
     const uint32_t wcount = ((nxb - home + PCR_TILE_SUB - 1) / PCR_TILE_SUB) * 4;
     int r = 0, sr = 0;
     // block-local state
-    const int64_t lspan = (((a.n + 7) >> 3) + 63) & ~(int64_t)63;
+    const int64_t lspan = (((a.n + 7) >> 3) + (TP - 1)) & ~(int64_t)(TP - 1);
     for (;;) {
         int64_t first, end;
         if (LOCAL) {
@@ -422,7 +450,7 @@ __device__ __forceinline__ void nn_tile_loop(const LinArgs &a, Body &&body) {
             uint32_t k = 0;
             if (lane == 0) k = atomicAdd(&blk_next, 1u);               // ds_add_rtn_u32: no memory traffic
             k = __builtin_amdgcn_readfirstlane(k);
-            first = lo + ((int64_t)xb + (int64_t)k * nxb) * 64;
+            first = lo + ((int64_t)xb + (int64_t)k * nxb) * TP;
             if (first >= end) break;
         } else {
             bool got = false;
@@ -434,7 +462,7 @@ __device__ __forceinline__ void nn_tile_loop(const LinArgs &a, Body &&body) {
                 // static tiles of sub-span `sub`: PCR_TILE_STATIC_ROUNDS per home wave of that sub-span
                 const uint32_t hcount = ((nxb - sub + PCR_TILE_SUB - 1) / PCR_TILE_SUB) * 4;
                 const uint32_t nstatic = PCR_TILE_STATIC_ROUNDS * hcount;
-                const uint32_t ntiles = end > lo ? (uint32_t)((end - lo + 63) >> 6) : 0u;
+                const uint32_t ntiles = end > lo ? (uint32_t)((end - lo + (TP - 1)) / TP) : 0u;
                 uint32_t t;
                 if (sr < PCR_TILE_STATIC_ROUNDS) {
                     t = wrank + (uint32_t)sr * wcount;
@@ -445,7 +473,7 @@ __device__ __forceinline__ void nn_tile_loop(const LinArgs &a, Body &&body) {
                     if (lane == 0) t = atomicAdd(&a.tile_ctr[c * PCR_TILE_STRIDE], 1u);
                     t = __builtin_amdgcn_readfirstlane(t) + nstatic;
                 }
-                first = lo + (int64_t)t * 64;
+                first = lo + (int64_t)t * TP;
                 if (first < end) { got = true; break; }
             }
             if (!got) break;
@@ -454,62 +482,234 @@ __device__ __forceinline__ void nn_tile_loop(const LinArgs &a, Body &&body) {
     }
 }
 
-// one query per lane, every lane on its own (gathers): the general search.  HALO: the target has the
-// extended per-cell lists and ring 0 reads those (nn_ring0).
-template <int VOXEL, int SEED, int HALO>
-__device__ __forceinline__ void nn_tile_perlane(const LinArgs &a, const PoseK &P, int64_t first, int64_t end) {
-    const int64_t i = first + (threadIdx.x & 63);
-    if (i >= end) return;
+// One query: scan point i, on its own lane (gathers): the general search.  HALO: the target has the extended
+// per-cell lists and ring 0 reads those (nn_ring0).
+// TRACK = 0: the match is gated here (PCR_NONE = no correspondence) -- nothing else is left behind.
+// TRACK = 1 (certified reuse): the UNGATED exact neighbour is stored together with lb2 = a lower bound on the
+// distance from the transformed point to every other target point, for k_certify of the next pass.  A point
+// that moved less than mu since the previous pass searches up to mu beyond its match to make that bound useful;
+// one that moved more searches exactly like the plain kernel (its bound then carries no margin).
+template <int VOXEL, int HALO, int TRACK>
+__device__ __forceinline__ void nn_point(const LinArgs &a, const PoseK &P, const PoseQ &Q, int64_t i) {
     const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
-    uint32_t pj = PCR_NONE;
-    if (SEED) pj = a.nn_j[i];
     float tx, ty, tz;
     xform(P, x, y, z, tx, ty, tz);
-    uint32_t bj = PCR_NONE, bo = PCR_NONE;
-    bool ok;
-    if (!VOXEL) {
-        float best = a.bound2_f;
-#if PCR_NN_ABLATE == 1
-        bo = bj = __float_as_uint(tx + ty + tz) & 0xffffu; best = 0.f;
-#elif PCR_NN_ABLATE == 2
-        { NNCell<float> c = nn_cell<float>(a.gf, tx, ty, tz, a.bound2_f);
-          (void)nn_ring0<float, PtF, false, HALO != 0>(a.gf, a.pts, a.cell_start, c, tx, ty, tz, best, bj, bo); }
-#else
-        if (SEED && pj != PCR_NONE) nn_test<float, PtF>(a.pts[pj], pj, tx, ty, tz, best, bj, bo);
-        nn_search<float, PtF, false, true, HALO != 0>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
-#endif
-        ok = bo != PCR_NONE && __builtin_sqrtf(best) < a.md_f;
-    } else {
-        double best = a.bound2_d;
-        if (SEED && pj != PCR_NONE) nn_test<double, PtD>(a.means[pj], pj, (double)tx, (double)ty, (double)tz, best, bj, bo);
-        nn_search<double, PtD, false, true>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz, a.bound2_d, best, bj, bo);
-        ok = bo != PCR_NONE && __builtin_sqrt(best) < a.md_d;
+    float mu = 0.f;
+    if (TRACK) {
+        float ux, uy, uz;
+        xform(Q, x, y, z, ux, uy, uz);
+        const float m = __builtin_sqrtf(dist2_f32(tx - ux, ty - uy, tz - uz));
+        mu = m < a.mu_f ? a.mu_f : 0.f;                    // (a NaN motion compares false: no margin)
     }
-    a.nn_j[i] = ok ? bj : PCR_NONE;
+    uint32_t bj = PCR_NONE, bo = PCR_NONE;
+    // a wave none of whose points moved little enough to be worth a margin runs the PLAIN search (second-best
+    // tracking costs 20-37 % of a far-pose search): then every other point is no closer than the match, lb2 = d1
+    const bool track = TRACK && __any(mu > 0.f);
+    if (!VOXEL) {
+        float best = a.bound2_f, lb2q;
+        if (track) {
+            NNTrack<float> tk;
+            nn_track_init<float>(tk, a.bound2_f, mu);
+            nn_search<float, PtF, false, false, HALO != 0, true>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo, nullptr, &tk);
+            lb2q = fminf(tk.second, tk.pmin);
+        } else {
+            nn_search<float, PtF, false, false, HALO != 0, false>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
+            lb2q = best;
+        }
+        if (TRACK) {
+            a.nn_j[i] = bo != PCR_NONE ? bj : PCR_NONE;
+            a.lb2[i] = __builtin_sqrtf(lb2q) * 0.99999f;
+        } else {
+            const bool ok = bo != PCR_NONE && __builtin_sqrtf(best) < a.md_f;
+            a.nn_j[i] = ok ? bj : PCR_NONE;
+        }
+    } else {
+        double best = a.bound2_d, lb2q;
+        if (track) {
+            NNTrack<double> tk;
+            nn_track_init<double>(tk, a.bound2_d, (double)mu);
+            nn_search<double, PtD, false, false, false, true>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz,
+                                                             a.bound2_d, best, bj, bo, nullptr, &tk);
+            lb2q = fmin(tk.second, tk.pmin);
+        } else {
+            nn_search<double, PtD, false, false, false, false>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz,
+                                                              a.bound2_d, best, bj, bo);
+            lb2q = best;
+        }
+        if (TRACK) {
+            a.nn_j[i] = bo != PCR_NONE ? bj : PCR_NONE;
+            a.lb2[i] = (float)(__builtin_sqrt(lb2q) * 0.99999);
+        } else {
+            const bool ok = bo != PCR_NONE && __builtin_sqrt(best) < a.md_d;
+            a.nn_j[i] = ok ? bj : PCR_NONE;
+        }
+    }
 }
 
+// ---- certified reuse of the previous pass' matches ------------------------------------------------
+// Registration.align (registration.py:89-111) repeats the full search every iteration although the converged
+// tail moves the scan by millimetres.  Between two passes over the same scan and target:
+//   * the previous pass left, per scan point, its exact nearest neighbour x1 (nn_j) and lb2 <= |q - y| for every
+//     other target point y, q being the point under the previous pose (a tracking search: nn_point<TRACK>);
+//   * under the new pose the point sits at q', m = |q' - q| away, so |q' - y| >= lb2 - m for every y != x1
+//     (triangle inequality);  if |q' - x1| < lb2 - m, x1 is still the strict, unique nearest neighbour --
+//     exactly what a fresh search would return -- and lb2 - m is the new bound;
+//   * a point that had nothing inside the search bound keeps that state while lb2 - m stays above the gate.
+// k_certify evaluates this for every point (one gather of the old match, no search), writes the new bounds and
+// a bit mask of the points it could NOT certify; k_nn_scan<LIST> then searches only those, compacted so that the
+// lanes of a wave stay dense; the reduce kernel is the one of every other pass, so the sums are bit-identical to
+// a pass that searched everything.  Everything is float32 arithmetic on the float32 positions the search itself
+// uses; the relative slacks (1e-5) cover the rounding of the distances (~1e-7) many times over.
+template <int VOXEL>
+__global__ void __launch_bounds__(256) k_certify(const LinArgs a) {
+    PoseK P;
+    PoseQ Q;
+    if (!load_pose<false>(a, P)) return;
+    load_prev(a, Q);
+    const TileIter it(a);
+    const int lane = threadIdx.x & 63;
+    uint32_t marked = 0;
+    for (int64_t i0 = it.base - threadIdx.x; i0 < it.end; i0 += it.stride) {
+        const int64_t i = i0 + threadIdx.x;
+        const bool live = i < it.end;
+        bool cert = false;
+        if (live) {
+            const uint32_t j = a.nn_j[i];
+            const float lb = a.lb2[i];
+            const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
+            float tx, ty, tz, ux, uy, uz;
+            xform(P, x, y, z, tx, ty, tz);
+            xform(Q, x, y, z, ux, uy, uz);
+            const float m = __builtin_sqrtf(dist2_f32(tx - ux, ty - uy, tz - uz)) * 1.00001f;
+            const float lbn = (lb - m) * 0.999999f;
+            if (j != PCR_NONE) {
+                float d1;
+                if (!VOXEL) {
+                    const PtF q = a.pts[j];
+                    d1 = __builtin_sqrtf(dist2_f32(tx - q.x, ty - q.y, tz - q.z));
+                } else {
+                    const PtD q = a.means[j];
+                    const double dx = (double)tx - q.x, dy = (double)ty - q.y, dz = (double)tz - q.z;
+                    d1 = (float)__builtin_sqrt((dx * dx + dy * dy) + dz * dz);
+                }
+                cert = d1 * 1.00002f < lbn;
+            } else {
+                cert = lbn > a.md_f * 1.00001f;            // still nothing inside the gate
+            }
+            if (cert) a.lb2[i] = lbn;
+        }
+        const unsigned long long mask = __ballot(live && !cert);
+        const int64_t w0 = i0 + (threadIdx.x & ~63);          // first point of this wave's tile
+        if (lane == 0 && w0 < it.end) a.umask[w0 >> 6] = mask;
+        marked += (uint32_t)__popcll(mask);
+    }
+    __shared__ uint32_t blk_marked;
+    if (threadIdx.x == 0) blk_marked = 0;
+    __syncthreads();
+    if (lane == 0) atomicAdd(&blk_marked, marked);
+    __syncthreads();
+    if (threadIdx.x == 0) a.ucnt[blockIdx.x] = blk_marked;
+}
+
+// A chunk of a LIST pass: PCR_LIST_CHUNK consecutive scan points = 16 mask words, handed to a BLOCK.  Wave 0 expands
+// the set bits into a list in LDS (lane l takes 16 bits: word l >> 2, quarter l & 3); the block's four waves then
+// search the listed points 64 at a time, round-robin -- the lanes stay dense however few points k_certify left
+// over, and a chunk with everything marked still runs four rounds per wave, like a full search.
+// (First version: one wave per chunk, 16 rounds in sequence -- 4.6x slower than the full search when nothing
+// certified.)
+#define PCR_LIST_CHUNK 1024
+template <int VOXEL, int HALO>
+__device__ __forceinline__ void nn_chunk_list(const LinArgs &a, const PoseK &P, const PoseQ &Q, uint16_t *lst, uint32_t *lst_n,
+                                              int64_t first, int64_t end) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {
+        const int64_t w = (first >> 6) + (lane >> 2);
+        const int64_t nwords = (a.n + 63) >> 6;
+        unsigned long long word = 0;
+        if (w < nwords && (w << 6) < end) word = a.umask[w];
+        uint32_t bits = (uint32_t)(word >> (16 * (lane & 3))) & 0xffffu;
+        const uint32_t cnt = (uint32_t)__popc(bits);
+        uint32_t incl = cnt;                                        // inclusive prefix sum over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, d, 64);
+            if (lane >= d) incl += v;
+        }
+        if (lane == 63) *lst_n = incl;
+        uint32_t pos = incl - cnt;
+        while (bits) {
+            const uint32_t b = (uint32_t)__builtin_ctz(bits);
+            lst[pos++] = (uint16_t)((lane << 4) | b);
+            bits &= bits - 1;
+        }
+    }
+    __syncthreads();
+    const uint32_t total = *lst_n;
+    for (uint32_t e = threadIdx.x; e < total; e += 256) nn_point<VOXEL, HALO, 1>(a, P, Q, first + (int64_t)lst[e]);
+    __syncthreads();                                                // (the list is rewritten by the next chunk)
+}
+
+// block-level hand-out of the chunks of a LIST pass: the XCD's span of the scan is dealt to the XCD's blocks through
+// one counter per XCD sub-span (same counters and the same sub-spans as nn_tile_loop; a block asks once per 1024
+// points, so the atomics do not matter here)
+template <typename Body>
+__device__ __forceinline__ void nn_chunk_loop(const LinArgs &a, Body &&body) {
+    const int xcd = (int)(blockIdx.x & 7);
+    const uint32_t xb = blockIdx.x >> 3;
+    const int64_t gspan = (((a.n + PCR_TILE_CTRS - 1) / PCR_TILE_CTRS) + (PCR_LIST_CHUNK - 1)) & ~(int64_t)(PCR_LIST_CHUNK - 1);
+    __shared__ uint32_t chunk_t;
+    for (int r = 0; r < PCR_TILE_SUB; ++r) {
+        const int c = xcd + 8 * (int)((xb + r) % PCR_TILE_SUB);
+        const int64_t lo = gspan * c;
+        const int64_t end = lo + gspan < a.n ? lo + gspan : a.n;
+        for (;;) {
+            if (threadIdx.x == 0) chunk_t = atomicAdd(&a.tile_ctr[c * PCR_TILE_STRIDE], 1u);
+            __syncthreads();
+            const int64_t first = lo + (int64_t)chunk_t * PCR_LIST_CHUNK;
+            __syncthreads();
+            if (first >= end) break;
+            body(first, first + PCR_LIST_CHUNK < end ? first + PCR_LIST_CHUNK : end);
+        }
+    }
+}
+
+// MODE: PCR_NN_FULL / PCR_NN_TRACK / PCR_NN_LIST
 // (5 waves per SIMD: the float64 centroid search sits at 101 VGPRs without the bound, which would cost it a
 // fifth of its occupancy and 10 % of its speed; the float32 search needs < 80 either way)
-template <int VOXEL, int SEED, int HALO, int LOCAL>
+template <int VOXEL, int HALO, int LOCAL, int MODE>
 __global__ void __launch_bounds__(256, 5) k_nn_scan(const LinArgs a) {
     PoseK P;
+    PoseQ Q;
     if (!load_pose<false>(a, P)) return;
-    nn_tile_loop<LOCAL>(a, [&](int64_t first, int64_t end) { nn_tile_perlane<VOXEL, SEED, HALO>(a, P, first, end); });
+    if (MODE != PCR_NN_FULL) load_prev(a, Q);
+    if (MODE == PCR_NN_LIST) {
+        __shared__ uint16_t lst[PCR_LIST_CHUNK];
+        __shared__ uint32_t lst_n;
+        nn_chunk_loop(a, [&](int64_t first, int64_t end) { nn_chunk_list<VOXEL, HALO>(a, P, Q, lst, &lst_n, first, end); });
+    } else {
+        nn_tile_loop<LOCAL, 64>(a, [&](int64_t first, int64_t end) {
+            const int64_t i = first + (threadIdx.x & 63);
+            if (i < end) nn_point<VOXEL, HALO, MODE == PCR_NN_TRACK>(a, P, Q, i);
+        });
+    }
 }
 
 // host-side choice of the instantiation
-template <int VOXEL>
-static void launch_nn_scan(bool seed, bool halo, bool local, dim3 grid, hipStream_t st, const LinArgs &a) {
+template <int VOXEL, int MODE>
+static void launch_nn_scan_mode(bool halo, bool local, dim3 grid, hipStream_t st, const LinArgs &a) {
     const dim3 block(256);
-#define PCR_NN_CASE(S, H, L) hipLaunchKernelGGL((k_nn_scan<VOXEL, S, (VOXEL ? 0 : H), L>), grid, block, 0, st, a)
-    if (seed) {
-        if (halo) { if (local) PCR_NN_CASE(1, 1, 1); else PCR_NN_CASE(1, 1, 0); }
-        else { if (local) PCR_NN_CASE(1, 0, 1); else PCR_NN_CASE(1, 0, 0); }
-    } else {
-        if (halo) { if (local) PCR_NN_CASE(0, 1, 1); else PCR_NN_CASE(0, 1, 0); }
-        else { if (local) PCR_NN_CASE(0, 0, 1); else PCR_NN_CASE(0, 0, 0); }
-    }
+#define PCR_NN_CASE(H, L) hipLaunchKernelGGL((k_nn_scan<VOXEL, (VOXEL ? 0 : H), L, MODE>), grid, block, 0, st, a)
+    if (halo) { if (local) PCR_NN_CASE(1, 1); else PCR_NN_CASE(1, 0); }
+    else { if (local) PCR_NN_CASE(0, 1); else PCR_NN_CASE(0, 0); }
 #undef PCR_NN_CASE
+}
+template <int VOXEL>
+static void launch_nn_scan(int mode, bool halo, bool local, dim3 grid, hipStream_t st, const LinArgs &a) {
+    switch (mode) {
+    case PCR_NN_FULL: launch_nn_scan_mode<VOXEL, PCR_NN_FULL>(halo, local, grid, st, a); break;
+    case PCR_NN_TRACK: launch_nn_scan_mode<VOXEL, PCR_NN_TRACK>(halo, local, grid, st, a); break;
+    default: launch_nn_scan_mode<VOXEL, PCR_NN_LIST>(halo, false, grid, st, a); break;
+    }
 }
 
 // ---- wave-cooperative search (point targets) ---------------------------------------------------
@@ -685,8 +885,8 @@ __global__ void __launch_bounds__(256) k_nn_coop(const LinArgs a) {
 #else
     PtF *stage = nullptr;
 #endif
-    if (a.sched_local) nn_tile_loop<1>(a, [&](int64_t first, int64_t end) { nn_tile_coop<SEED>(a, P, stage, first, end); });
-    else nn_tile_loop<0>(a, [&](int64_t first, int64_t end) { nn_tile_coop<SEED>(a, P, stage, first, end); });
+    if (a.sched_local) nn_tile_loop<1, 64>(a, [&](int64_t first, int64_t end) { nn_tile_coop<SEED>(a, P, stage, first, end); });
+    else nn_tile_loop<0, 64>(a, [&](int64_t first, int64_t end) { nn_tile_coop<SEED>(a, P, stage, first, end); });
 }
 
 // work counters of the search (instrumentation; same traversal as k_nn_scan<0>): out[0..3] = per-lane
@@ -744,6 +944,11 @@ struct FinArgs {
     double *host_out;          // optional: the same 29 values straight into pinned host memory ...
     volatile uint32_t *host_flag;   // ... followed by this sequence number (host spins on it)
     uint32_t seq;
+    // certified reuse: what the search of this pass did (PCR_NN_*, -1 = read it from the pose) and the per-block
+    // counts of k_certify; reported in out[29] (points searched by a LIST pass) and out[30] (mode)
+    int nn_mode;
+    const uint32_t *ucnt;
+    int n_ucnt;
     // device-resident Gauss-Newton loop (pcr_align; registration.py:89-111 behind the boundary)
     PoseDev *pose;             // NULL: plain pass
     int max_iter;
@@ -757,6 +962,17 @@ struct FinArgs {
 // pinned host memory followed by the sequence number; also re-arms the tile counters.
 __device__ __forceinline__ void finalize_emit(const FinArgs &f, const double *tot) {
     if (threadIdx.x < PCR_TILE_CTRS) f.tile_ctr[threadIdx.x * PCR_TILE_STRIDE] = 0;     // ready for the next k_nn_scan
+    // points k_certify left to the search (LIST passes)
+    __shared__ uint32_t listed;
+    const int mode = f.nn_mode;
+    if (mode == PCR_NN_LIST) {
+        if (threadIdx.x == 0) listed = 0;
+        __syncthreads();
+        uint32_t v = 0;
+        for (int b = threadIdx.x; b < f.n_ucnt; b += blockDim.x) v += f.ucnt[b];
+        if (v) atomicAdd(&listed, v);
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
         if (f.kind != PCR_ICP) {
             for (int i = 0; i < 29; ++i) f.out[i] = tot[i];
@@ -783,9 +999,9 @@ __device__ __forceinline__ void finalize_emit(const FinArgs &f, const double *to
             for (int i = 0; i < 3; ++i) { f.out[21 + i] = tot[10 + i]; f.out[24 + i] = tot[13 + i]; }
             f.out[27] = tot[16]; f.out[28] = cnt;
         }
-        f.out[29] = 0; f.out[30] = 0; f.out[31] = 0;
+        f.out[29] = mode == PCR_NN_LIST ? (double)listed : 0.0; f.out[30] = (double)mode; f.out[31] = 0;
         if (f.host_out) {
-            for (int i = 0; i < 29; ++i) f.host_out[i] = f.out[i];
+            for (int i = 0; i < 31; ++i) f.host_out[i] = f.out[i];
             __threadfence_system();
             *f.host_flag = f.seq;
         }
@@ -1088,7 +1304,8 @@ struct Pass {
     FinArgs f;
     bool one_kernel;     // fused search + reduce kernel (variant 0, or variant 2 on a small scan)
     bool fused_fin;      // the fold of the block partials inside the producing kernel instead of k_finalize
-    bool seed;           // the scan holds matches against this very target: seed the search with them
+    int nn_mode;         // PCR_NN_FULL / TRACK / LIST
+    bool reuse_ready;    // the scan has the buffers of the certified-reuse path
 };
 
 static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, double max_dist, unsigned flags) {
@@ -1117,6 +1334,29 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
         HIP_TRY(hipMalloc(&s->nn_j, sizeof(uint32_t) * (size_t)(s->n > 0 ? s->n : 1)));
         s->nn_serial = 0;
     }
+    const int nblocks_split = [&] {
+        int nb = choose_blocks(ctx, s->n);
+        if (nb > ctx->num_cu * 4) nb = ctx->num_cu * 4;
+        nb &= ~7;
+        return nb < 8 ? 8 : nb;
+    }();
+    ps->reuse_ready = false;
+    if (!one_kernel && ctx->reuse != 0 && ctx->nn_mode == 0 && s->n > 0) {
+        if (!s->lb2) {
+            const size_t words = (((size_t)s->n + 63) / 64 + 31) & ~(size_t)15;     // whole 16-word chunks + slack
+            HIP_TRY(hipMalloc(&s->lb2, sizeof(float) * (size_t)s->n));
+            HIP_TRY(hipMalloc(&s->umask, sizeof(unsigned long long) * words));
+            HIP_TRY(hipMemsetAsync(s->umask, 0, sizeof(unsigned long long) * words, ctx->stream));
+            s->track_valid = false;
+        }
+        if (s->ucnt_cap < nblocks_split) {
+            if (s->ucnt) HIP_TRY(hipFree(s->ucnt));
+            s->ucnt = nullptr; s->ucnt_cap = 0;
+            HIP_TRY(hipMalloc(&s->ucnt, sizeof(uint32_t) * (size_t)nblocks_split));
+            s->ucnt_cap = nblocks_split;
+        }
+        ps->reuse_ready = true;
+    }
     ps->ctx = ctx; ps->t = t; ps->s = s; ps->kind = kind; ps->one_kernel = one_kernel;
     LinArgs &a = ps->a;
     memset(&a, 0, sizeof a);
@@ -1131,14 +1371,17 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
     a.nblocks = choose_blocks(ctx, s->n);
     a.partials = ctx->d_partials;
     a.nn_j = s->nn_j; a.tile_ctr = ctx->d_tile_ctr + 9 * 16;
+    a.lb2 = s->lb2; a.umask = s->umask; a.ucnt = s->ucnt;
+    a.mu_f = (float)(ctx->reuse_mu * (t->is_voxel ? t->gd.h : (double)t->gf.h));
     if (!one_kernel && a.nblocks > ctx->num_cu * 4) a.nblocks = ctx->num_cu * 4;   // k_reduce streams: 4 blocks/CU
     // TileIter and the ticket counts of k_reduce_finalize need a multiple of 8 blocks
     a.nblocks &= ~7;
     if (a.nblocks < 8) a.nblocks = 8;
     ps->fused_fin = ctx->fuse_finalize;
-    ps->seed = !one_kernel && ctx->nn_mode >= 1 && s->nn_serial == t->serial && s->nn_serial != 0;
+    ps->nn_mode = PCR_NN_FULL;
     FinArgs &f = ps->f;
     memset(&f, 0, sizeof f);
+    f.ucnt = s->ucnt; f.n_ucnt = a.nblocks;
     f.partials = ctx->d_partials; f.tile_ctr = ctx->d_tile_ctr + 9 * 16; f.tickets = ctx->d_tile_ctr; f.nblocks = a.nblocks; f.kind = kind; f.out = ctx->d_out;
     return PCR_OK;
 }
@@ -1152,6 +1395,37 @@ static void pass_set_host_pose(Pass *ps, const double T[16]) {
         ps->a.hp.t32[i] = (float)T[4 * i + 3];
     }
     ps->a.pose = nullptr; ps->f.pose = nullptr;
+    if (ps->s->pose_valid) {
+        const double *Tp = ps->s->prev_T;
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) ps->a.hq.r32[3 * i + j] = (float)Tp[4 * i + j];
+            ps->a.hq.t32[i] = (float)Tp[4 * i + 3];
+        }
+    }
+}
+
+// What the search of a pass does (gn_math.h: gn_choose_nn_mode) and the search bound that goes with it: a tracking
+// search looks 5 % beyond the gate, so that a point with nothing in reach can be certified "still nothing" later.
+static void pass_set_mode(Pass *ps, int mode) {
+    ps->nn_mode = mode;
+    ps->f.nn_mode = mode;
+    const double md = ps->a.md_d;
+    const double bound = mode == PCR_NN_FULL ? md * (1.0 + 1e-6) : md * 1.05;
+    ps->a.bound2_f = (float)(bound * bound); ps->a.bound2_d = bound * bound;
+}
+
+static int host_choose_mode(const Pass *ps, const double T[16], double *motion_out) {
+    const pcr_context *ctx = ps->ctx;
+    const pcr_scan *s = ps->s;
+    const pcr_target *t = ps->t;
+    *motion_out = -1.0;
+    if (!ps->reuse_ready) return PCR_NN_FULL;
+    const int have_prev = s->pose_valid && s->nn_serial == t->serial && s->nn_serial != 0;
+    if (!have_prev) return PCR_NN_FULL;
+    const double h = t->is_voxel ? t->gd.h : (double)t->gf.h;
+    const double m = gn_typical_motion(s->prev_T, T, s->bb_c, s->bb_e);
+    *motion_out = m;
+    return gn_choose_nn_mode(ctx->reuse, have_prev, s->track_valid ? 1 : 0, m, s->last_motion, ctx->reuse_tau * h);
 }
 
 template <int KIND>
@@ -1188,33 +1462,37 @@ static pcr_status pass_enqueue(Pass *ps) {
 #undef PCR_LIN_CASE
         pcr_prof_end(ctx, &ev);
     } else {
+        const bool vox = ps->t->is_voxel != 0;
+        const int mode = ps->nn_mode;
+        if (mode == PCR_NN_LIST) {
+            // the previous matches that are provably still exact need no search (k_certify)
+            pcr_prof_begin(ctx, PCR_K_CERTIFY, &ev);
+            RoctxRange range("pcr:certify");
+            if (vox) hipLaunchKernelGGL(k_certify<1>, grid, block, 0, ctx->stream, a);
+            else hipLaunchKernelGGL(k_certify<0>, grid, block, 0, ctx->stream, a);
+            pcr_prof_end(ctx, &ev);
+        }
         pcr_prof_begin(ctx, PCR_K_NN, &ev);
         {   // exactly one resident generation of waves; they share the tiles dynamically
             RoctxRange range("pcr:nn_search");
-            const bool vox = ps->t->is_voxel != 0;
             int64_t nb = (int64_t)ctx->num_cu * ctx->nn_blocks_per_cu[vox ? 1 : (ctx->nn_mode == 2 ? 2 : 0)];
-            const int64_t need = ((a.n + 63) / 64 + 3) / 4;
+            // tiles of the hand-out: 64 points per wave, or the 1024-point chunks of a LIST pass (one block per chunk)
+            const int64_t tiles = mode == PCR_NN_LIST ? (a.n + PCR_LIST_CHUNK - 1) / PCR_LIST_CHUNK : (a.n + 63) / 64;
+            const int64_t need = mode == PCR_NN_LIST ? tiles : (tiles + 3) / 4;
             if (nb > need) nb = need;
             nb = (nb + 7) & ~(int64_t)7;
             if (nb < 8) nb = 8;
             const dim3 nn_grid((unsigned)nb);
-            {   // hand-out policy: at most ~1.5 tiles per launched wave -> block-local (nn_tile_loop)
-                const int64_t tiles = (a.n + 63) / 64;
-                int local = tiles * 2 <= nb * 4 * 3 ? 1 : 0;
-                const char *e = getenv("PCR_TILE_LOCAL");
-                if (e && *e) local = atoi(e) != 0;
-                ps->a.sched_local = local;
-            }
+            // hand-out policy: at most ~1.5 tiles per launched wave -> block-local (nn_tile_loop)
+            ps->a.sched_local = ctx->tile_local >= 0 ? ctx->tile_local : (tiles * 2 <= nb * 4 * 3 ? 1 : 0);
             if (!vox && ctx->nn_mode == 2) {
-                if (ps->seed) hipLaunchKernelGGL((k_nn_coop<1>), nn_grid, block, 0, ctx->stream, a);
-                else hipLaunchKernelGGL((k_nn_coop<0>), nn_grid, block, 0, ctx->stream, a);
+                hipLaunchKernelGGL((k_nn_coop<0>), nn_grid, block, 0, ctx->stream, a);
             } else if (!vox) {
-                launch_nn_scan<0>(ps->seed, ps->t->cs_h != nullptr, ps->a.sched_local != 0, nn_grid, ctx->stream, a);
+                launch_nn_scan<0>(mode, ps->t->cs_h != nullptr, ps->a.sched_local != 0, nn_grid, ctx->stream, a);
             } else {
-                launch_nn_scan<1>(ps->seed, false, ps->a.sched_local != 0, nn_grid, ctx->stream, a);
+                launch_nn_scan<1>(mode, false, ps->a.sched_local != 0, nn_grid, ctx->stream, a);
             }
             ps->s->nn_serial = ps->t->serial;      // nn_j now holds matches against this target
-            ps->seed = ctx->nn_mode >= 1;          // ... which the next pass of a loop may start from
         }
         pcr_prof_end(ctx, &ev);
         pcr_prof_begin(ctx, PCR_K_REDUCE, &ev);
@@ -1267,6 +1545,9 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
     PCR_TRY(pass_setup(&ps, t, s, kind, max_dist, flags));
     pcr_context *ctx = ps.ctx;
     pass_set_host_pose(&ps, T);
+    double motion = -1.0;
+    const int mode = ps.one_kernel ? PCR_NN_FULL : host_choose_mode(&ps, T, &motion);
+    pass_set_mode(&ps, mode);
     const bool use_comm = ctx->comm != nullptr && !(flags & PCR_FLAG_LOCAL_ONLY);
     // single GPU: the finalize step writes the result and a sequence number straight into pinned host
     // memory (no copy command, no stream query); with a communicator the all-reduce sits in between
@@ -1277,6 +1558,12 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
     const uint32_t seq = ++ctx->seq;
     ps.f.seq = seq;
     PCR_TRY(pass_enqueue(&ps));
+    // what this pass leaves behind for the next one over the same scan
+    memcpy(s->prev_T, T, sizeof s->prev_T);
+    s->pose_valid = !ps.one_kernel;
+    s->track_valid = mode != PCR_NN_FULL;
+    s->last_mode = mode; s->last_motion = motion; s->last_marked = mode == PCR_NN_LIST ? -1 : 0;
+    s->st_passes[mode] += 1;
 
     bool flagged = direct;
     if (use_comm) {
@@ -1296,12 +1583,20 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
     if (flagged) {
         PCR_TRY(wait_host_word(ctx, [&] { return *flag == seq; }, "finalize kernel"));
         for (int i = 0; i < 29; ++i) out[i] = ctx->h_out[i];
+        if (mode == PCR_NN_LIST && direct) {
+            s->last_marked = (int64_t)ctx->h_out[29];
+            s->st_marked += s->last_marked; s->st_listed_of += s->n;
+        }
         retire_completed(ctx);
         return PCR_OK;
     }
-    HIP_TRY(hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(double) * 29, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(double) * 31, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < 29; ++i) out[i] = ctx->h_out[i];
+    if (mode == PCR_NN_LIST && !use_comm) {
+        s->last_marked = (int64_t)ctx->h_out[29];
+        s->st_marked += s->last_marked; s->st_listed_of += s->n;
+    }
     return PCR_OK;
 }
 
@@ -1323,6 +1618,7 @@ pcr_status pcr_run_align(pcr_target *t, pcr_scan *s, int kind, const double T_in
         if (iterations) *iterations = 0;
         return PCR_OK;
     }
+    s->pose_valid = false; s->track_valid = false;       // (the loop's own bookkeeping lives in PoseDev)
     if (ctx->trace_cap < max_iter) {
         if (ctx->d_trace) HIP_TRY(hipFree(ctx->d_trace));
         ctx->d_trace = nullptr; ctx->trace_cap = 0;

@@ -49,33 +49,88 @@ __device__ __forceinline__ float dist2_f32(float dx, float dy, float dz) {
     return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
 
+// ---- tracking searches (certified reuse of a match by the NEXT pass, kernels.hip: k_certify) -------
+// A TRACK search also returns a lower bound on the distance from the query to every target point
+// OTHER than the winner.  It keeps `second` = the smallest squared distance seen on any candidate that
+// is not the winner, and prunes with  prune = min(second, (sqrt(best) + mu)^2)  instead of `best`: every
+// point it never looked at is then farther than sqrt(prune) at the time it was skipped, so
+//     lb2^2 = min(second, smallest prune value ever used)
+// bounds all the others from below.  mu (per lane) caps the price: the search looks at most mu beyond
+// the match (mu = 0: exactly the plain search, and lb2 = the match distance, i.e. no margin).
+template <typename Real>
+struct NNTrack {
+    Real second;      // min squared distance over examined candidates other than the current winner
+    Real prune;       // current pruning bound (>= best)
+    Real pmin;        // smallest pruning bound used so far
+    Real two_mu, mu2; // 2 mu, mu^2
+};
+
+template <typename Real>
+__device__ __forceinline__ void nn_track_init(NNTrack<Real> &tk, Real bound2, Real mu) {
+    tk.second = bound2; tk.prune = bound2; tk.pmin = bound2; tk.two_mu = mu + mu; tk.mu2 = mu * mu;
+}
+
 // The search tracks (squared distance, original index) -- the oracle's tie rule -- and, for the reduce
 // kernel's gather, the index `j` of the winner in the array it was read from (the cell-sorted array, or
 // an extended list whose entries are translated through Geom::j_h right after ring 0).
-template <typename Real, typename PT>
+template <typename Real, typename PT, bool TRACK = false>
 __device__ __forceinline__ void nn_test(const PT &p, uint32_t j, Real qx, Real qy, Real qz,
-                                        Real &best, uint32_t &bj, uint32_t &borig) {
+                                        Real &best, uint32_t &bj, uint32_t &borig, NNTrack<Real> *tk = nullptr) {
     const Real dx = qx - (Real)p.x, dy = qy - (Real)p.y, dz = qz - (Real)p.z;
     const Real d = (dx * dx + dy * dy) + dz * dz;
     const uint32_t o = pt_orig(p);
     // straight-line selects (bitwise, not short-circuit): no exec-mask juggling in the hot loop
     const bool take = (d < best) | ((d == best) & (o < borig));
+    if (TRACK) {
+        // the loser of this comparison is "some other point" -- unless the candidate IS the current winner
+        // seen again (batches over-read into the next cell, halo copies are revisited by ring 1)
+        const bool same = (d == best) & (o == borig);
+        const Real other = take ? best : d;
+        tk->second = same ? tk->second : fmin(tk->second, other);
+    }
     best = take ? d : best; bj = take ? j : bj; borig = take ? o : borig;
 }
 
 // float32 specialisation: d >= 0, so the bit patterns of squared distances order like the values and
 // (distance, original index) packs into ONE unsigned 64-bit key -- "closer, ties to the smaller
 // index" becomes a single 64-bit compare instead of three compares and two mask operations.
-template <>
-__device__ __forceinline__ void nn_test<float, float4>(const float4 &p, uint32_t j, float qx, float qy, float qz,
-                                                       float &best, uint32_t &bj, uint32_t &borig) {
+template <bool TRACK>
+__device__ __forceinline__ void nn_test_f32(const float4 &p, uint32_t j, float qx, float qy, float qz,
+                                            float &best, uint32_t &bj, uint32_t &borig, NNTrack<float> *tk) {
     const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
     const float d = dist2_f32(dx, dy, dz);
     const uint32_t o = pt_orig(p);
     const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | o;
     const unsigned long long cur = ((unsigned long long)__float_as_uint(best) << 32) | borig;
     const bool take = key < cur;
+    if (TRACK) {
+        const bool same = key == cur;
+        const float other = take ? best : d;
+        tk->second = same ? tk->second : fminf(tk->second, other);
+    }
     best = take ? d : best; bj = take ? j : bj; borig = take ? o : borig;
+}
+template <>
+__device__ __forceinline__ void nn_test<float, float4, false>(const float4 &p, uint32_t j, float qx, float qy, float qz,
+                                                              float &best, uint32_t &bj, uint32_t &borig, NNTrack<float> *tk) {
+    nn_test_f32<false>(p, j, qx, qy, qz, best, bj, borig, tk);
+}
+template <>
+__device__ __forceinline__ void nn_test<float, float4, true>(const float4 &p, uint32_t j, float qx, float qy, float qz,
+                                                             float &best, uint32_t &bj, uint32_t &borig, NNTrack<float> *tk) {
+    nn_test_f32<true>(p, j, qx, qy, qz, best, bj, borig, tk);
+}
+
+// refresh the pruning bound of a tracking search after `best` / `second` may have changed
+template <typename Real>
+__device__ __forceinline__ void nn_track_refresh(NNTrack<Real> &tk, Real best) {
+    typedef RealTraits<Real> RT;
+    // (sqrt(best) + mu)^2; any value >= best is a valid bound, so the fast sqrt is fine: what is recorded in
+    // pmin is the value that was actually used
+    const Real infl = best + (tk.two_mu * RT::sqrt_fast(best) + tk.mu2);
+    const Real p = fmin(tk.second, infl);
+    tk.prune = p;
+    tk.pmin = fmin(tk.pmin, p);
 }
 
 // The search is latency-bound (one L2 round trip per dependent load, ~500 cycles): candidates are
@@ -87,17 +142,19 @@ __device__ __forceinline__ void nn_test<float, float4>(const float4 &p, uint32_t
 #ifndef PCR_NN_BATCH
 #define PCR_NN_BATCH 4   // measured: 8 costs occupancy (101 VGPR) and is slower except for tiny scans
 #endif
-template <typename Real, typename PT>
+template <typename Real, typename PT, bool TRACK = false>
 __device__ __forceinline__ void nn_scan_range(const PT *__restrict__ pts, uint32_t s, uint32_t e,
-                                              Real qx, Real qy, Real qz, Real &best, uint32_t &bj, uint32_t &borig) {
+                                              Real qx, Real qy, Real qz, Real &best, uint32_t &bj, uint32_t &borig,
+                                              NNTrack<Real> *tk = nullptr) {
     for (uint32_t j = s; j < e; j += PCR_NN_BATCH) {
         const PT *__restrict__ b = pts + j;
         PT p[PCR_NN_BATCH];
 #pragma unroll
         for (int u = 0; u < PCR_NN_BATCH; ++u) p[u] = b[u];
 #pragma unroll
-        for (int u = 0; u < PCR_NN_BATCH; ++u) nn_test<Real, PT>(p[u], j + u, qx, qy, qz, best, bj, borig);
+        for (int u = 0; u < PCR_NN_BATCH; ++u) nn_test<Real, PT, TRACK>(p[u], j + u, qx, qy, qz, best, bj, borig, tk);
     }
+    if (TRACK) nn_track_refresh<Real>(*tk, best);
 }
 
 // Per-lane work counters, compiled in only for pcr_nn_counters (STATS = true).
@@ -143,10 +200,11 @@ __device__ __forceinline__ NNCell<Real> nn_cell(const Geom<Real> &g, Real qx, Re
 // nearly converged query (residual << halo) is certified by ring 0 alone and never enters the ring
 // loop: without the halo the ~8 % of lanes that sit closer to a face than to their match drag their
 // whole wave through ring 1 (measured: 75 % of the wave time at the converged pose).
-template <typename Real, typename PT, bool STATS = false, bool HALO = false>
+template <typename Real, typename PT, bool STATS = false, bool HALO = false, bool TRACK = false>
 __device__ __forceinline__ int nn_ring0(const Geom<Real> &g, const PT *__restrict__ pts, const uint32_t *__restrict__ cs,
                                         NNCell<Real> &c, Real qx, Real qy, Real qz,
-                                        Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr) {
+                                        Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr,
+                                        NNTrack<Real> *tk = nullptr) {
     if (c.k0 != 0) return c.k0;                   // outside the grid box: rings below k0 hold no cells
     const uint32_t own = ((uint32_t)c.cz * (uint32_t)g.ny + (uint32_t)c.cy) * (uint32_t)g.nx + (uint32_t)c.cx;
     constexpr bool ext = HALO;                   // (HALO launches only happen for targets that have the lists)
@@ -160,17 +218,20 @@ __device__ __forceinline__ int nn_ring0(const Geom<Real> &g, const PT *__restric
             // the extended list holds COPIES: track the position in it, then translate the winner to its
             // cell-sorted index (j_h is laid out like the lists, so neighbouring queries share its lines)
             uint32_t ej = PCR_NONE;
-            nn_scan_range<Real, PT>((const PT *)g.pts_h, s_, e_, qx, qy, qz, best, ej, borig);
+            nn_scan_range<Real, PT, TRACK>((const PT *)g.pts_h, s_, e_, qx, qy, qz, best, ej, borig, tk);
             if (ej != PCR_NONE) bj = g.j_h[ej];
             c.reach0 = g.halo;
         } else {
-            nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
+            nn_scan_range<Real, PT, TRACK>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
         }
         return 1;
     }
     if (g.seed) {                                 // a real point nearby bounds the search from the start
         const uint32_t j0 = g.seed[own];
-        if (j0 != PCR_NONE) nn_test<Real, PT>(pts[j0], j0, qx, qy, qz, best, bj, borig);
+        if (j0 != PCR_NONE) {
+            nn_test<Real, PT, TRACK>(pts[j0], j0, qx, qy, qz, best, bj, borig, tk);
+            if (TRACK) nn_track_refresh<Real>(*tk, best);
+        }
     }
     return gap;                                   // rings closer than `gap` are empty
 }
@@ -184,17 +245,20 @@ __device__ __forceinline__ bool nn_certified(const Geom<Real> &g, const NNCell<R
 }
 
 // Rings kstart (>= 1) .. kmax.
-template <typename Real, typename PT, bool STATS = false>
+// (a tracking search prunes with tk->prune wherever the plain one prunes with best: PB below)
+template <typename Real, typename PT, bool STATS = false, bool TRACK = false>
 __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restrict__ pts, const uint32_t *__restrict__ cs,
                                          const NNCell<Real> &c, int kstart, Real qx, Real qy, Real qz,
-                                         Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr) {
+                                         Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr,
+                                         NNTrack<Real> *tk = nullptr) {
+#define PB (TRACK ? tk->prune : best)
     typedef RealTraits<Real> RT;
     const Real lim = (Real)1.0e9;
     const int cx = c.cx, cy = c.cy, cz = c.cz;
     const Real fx = c.fx, fy = c.fy, fz = c.fz;
     const uint32_t unx = (uint32_t)g.nx, plane = (uint32_t)g.ny * (uint32_t)g.nx;   // ncells < 2^32
     for (int k = kstart; k <= c.kmax; ++k) {
-        if (nn_certified<Real>(g, c, k, best)) break;
+        if (nn_certified<Real>(g, c, k, PB)) break;
         if (STATS) st->rings++;
         const int zlo = max(cz - k, 0), zhi = min(cz + k, g.nz - 1);
         const int ylo = max(cy - k, 0), yhi = min(cy + k, g.ny - 1);
@@ -208,7 +272,7 @@ __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restri
             Real dzm = dzc == 0 ? (Real)0 : (dzc > 0 ? (Real)dzc * g.h - fz : (Real)(-dzc - 1) * g.h + fz);
             dzm = fmax(dzm - g.slack, (Real)0);
             const Real dz2 = dzm * dzm;
-            if (dz2 > best) continue;
+            if (dz2 > PB) continue;
             const bool zshell = (dzc == k) || (dzc == -k);
             uint32_t row = (uint32_t)z * plane + (uint32_t)ylo * unx;
             for (int y = ylo; y <= yhi; ++y, row += unx) {
@@ -216,12 +280,12 @@ __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restri
                 Real dym = dyc == 0 ? (Real)0 : (dyc > 0 ? (Real)dyc * g.h - fy : (Real)(-dyc - 1) * g.h + fy);
                 dym = fmax(dym - g.slack, (Real)0);
                 const Real dyz2 = dz2 + dym * dym;
-                if (dyz2 > best) { if (STATS) st->rows_pruned++; continue; }
+                if (dyz2 > PB) { if (STATS) st->rows_pruned++; continue; }
                 if (zshell || dyc == k || dyc == -k) {
                     int xl = xlo, xh = xhi;
-                    if (best < RT::inf()) {                 // clip the row to the remaining budget
+                    if (PB < RT::inf()) {                   // clip the row to the remaining budget
                         // approximate sqrt is fine here: the clip only has to be conservative
-                        const Real xr = RT::sqrt_fast(best - dyz2) * (Real)1.000002 + g.slack;
+                        const Real xr = RT::sqrt_fast(PB - dyz2) * (Real)1.000002 + g.slack;
                         const Real a = (qx - xr - g.ox) * g.inv_h, b = (qx + xr - g.ox) * g.inv_h;
                         if (a > (Real)xl) xl = (int)RT::floor_(fmin(a, lim));
                         if (b < (Real)xh) xh = (int)RT::floor_(fmax(b, -lim));
@@ -229,37 +293,41 @@ __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restri
                     if (xl <= xh) {
                         const uint32_t s_ = cs[row + (uint32_t)xl] & g.cs_mask, e_ = cs[row + (uint32_t)xh + 1u] & g.cs_mask;
                         if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-                        nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
+                        nn_scan_range<Real, PT, TRACK>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
                     }
                 } else {                                    // interior row of the ring: its two end cells
-                    if (xa_in && dyz2 + dxa <= best) {
+                    if (xa_in && dyz2 + dxa <= PB) {
                         const uint32_t s_ = cs[row + (uint32_t)xa] & g.cs_mask, e_ = cs[row + (uint32_t)xa + 1u] & g.cs_mask;
                         if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-                        nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
+                        nn_scan_range<Real, PT, TRACK>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
                     }
-                    if (xb_in && dyz2 + dxb <= best) {
+                    if (xb_in && dyz2 + dxb <= PB) {
                         const uint32_t s_ = cs[row + (uint32_t)xb] & g.cs_mask, e_ = cs[row + (uint32_t)xb + 1u] & g.cs_mask;
                         if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-                        nn_scan_range<Real, PT>(pts, s_, e_, qx, qy, qz, best, bj, borig);
+                        nn_scan_range<Real, PT, TRACK>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
                     }
                 }
             }
         }
     }
+#undef PB
 }
 
 // On return: borig = ORIGINAL index of the nearest point (PCR_NONE if nothing closer than
 // sqrt(bound2)), best = its squared distance, bj = its cell-sorted index.
 // SEEDED: best / bj / borig come in holding a real target point (any point is an exact upper bound:
 // the search then only has to look inside that radius) or (bound2, PCR_NONE, PCR_NONE).
-template <typename Real, typename PT, bool STATS = false, bool SEEDED = false, bool HALO = false>
+// TRACK: `tk` was initialised with nn_track_init(tk, bound2, mu); on return min(tk->second, tk->pmin) is a lower
+// bound on the squared distance to every target point other than the winner (to every point if there is none).
+template <typename Real, typename PT, bool STATS = false, bool SEEDED = false, bool HALO = false, bool TRACK = false>
 __device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restrict__ pts,
                                           const uint32_t *__restrict__ cs,
                                           Real qx, Real qy, Real qz, Real bound2,
-                                          Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr) {
+                                          Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr,
+                                          NNTrack<Real> *tk = nullptr) {
     if (!SEEDED) { best = bound2; bj = PCR_NONE; borig = PCR_NONE; }
     NNCell<Real> c = nn_cell<Real>(g, qx, qy, qz, bound2);
-    const int kstart = nn_ring0<Real, PT, STATS, HALO>(g, pts, cs, c, qx, qy, qz, best, bj, borig, st);
-    nn_rings<Real, PT, STATS>(g, pts, cs, c, kstart, qx, qy, qz, best, bj, borig, st);
+    const int kstart = nn_ring0<Real, PT, STATS, HALO, TRACK>(g, pts, cs, c, qx, qy, qz, best, bj, borig, st, tk);
+    nn_rings<Real, PT, STATS, TRACK>(g, pts, cs, c, kstart, qx, qy, qz, best, bj, borig, st, tk);
 }
 

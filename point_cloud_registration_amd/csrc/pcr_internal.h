@@ -178,7 +178,12 @@ struct pcr_context {
     double *d_trace = nullptr;
     int trace_cap = 0;
     int variant = 0;
-    int nn_mode = 0;             // 0 per-lane search; 1 the same, seeded with the previous match; 2 wave-cooperative
+    int nn_mode = 0;             // 0 per-lane search; 2 wave-cooperative (developer builds)
+    // certified reuse of the previous pass' matches (see kernels.hip: choose_nn_mode)
+    int tile_local = -1;         // PCR_TILE_LOCAL (developer): force the hand-out policy of k_nn_scan; -1 = automatic
+    int reuse = 1;               // 0 off, 1 automatic, 2 forced (track + list whenever the state allows: tests)
+    double reuse_tau = 0.08;     // try it when the scan's typical motion since the last pass is below tau x cell size
+    double reuse_mu = 0.05;      // margin of the tracking search, x cell size
     uint64_t next_serial = 1;    // targets get unique serial numbers (validity of a scan's previous matches)
     bool fuse_finalize = true;   // k_reduce_finalize (PCR_FUSE_FINALIZE=0: k_reduce + k_finalize)
     uint32_t *d_tile_ctr = nullptr;     // per-XCD dynamic tile counters of k_nn_scan
@@ -236,7 +241,29 @@ struct pcr_scan {
     // next search against the SAME target (nn_serial)
     uint32_t *nn_j = nullptr;
     uint64_t nn_serial = 0;
+    // ---- certified reuse: state a pass leaves behind for the next one against the same target ----
+    // after a TRACK / LIST pass: nn_j[i] = exact nearest neighbour (ungated; PCR_NONE = nothing inside the
+    // search bound), lb2[i] = lower bound on the distance from the transformed point to every OTHER target point
+    float *lb2 = nullptr;
+    unsigned long long *umask = nullptr;   // 1 bit per scan point: not certified by k_certify -> search it
+    uint32_t *ucnt = nullptr;              // per k_certify block: points marked
+    int ucnt_cap = 0;
+    bool pose_valid = false;               // prev_T = pose of the last pass over this scan
+    double prev_T[16] = {0};
+    bool track_valid = false;              // nn_j / lb2 hold tracking results for target `nn_serial` at prev_T
+    float bb_c[3] = {0, 0, 0}, bb_e[3] = {0, 0, 0};   // bounding box of the scan: centre, half extents
+    // statistics (pcr_scan_reuse_stats): passes by mode, points marked / examined by LIST passes, last pass
+    int64_t st_passes[3] = {0, 0, 0};
+    int64_t st_marked = 0, st_listed_of = 0;
+    int last_mode = 0;
+    int64_t last_marked = 0;               // (-1: a LIST pass whose count was not read back)
+    double last_motion = -1;
 };
+
+// what a pass does with the matches of the previous one
+#define PCR_NN_FULL 0     // plain exact search of every point
+#define PCR_NN_TRACK 1    // exact search of every point that also records the margin to the runner-up
+#define PCR_NN_LIST 2     // k_certify proves most of the old matches still exact; tracking search of the rest
 
 // ---- index_build.hip
 pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n, float cell_hint, pcr_target *t);

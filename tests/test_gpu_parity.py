@@ -149,8 +149,8 @@ def test_linearize_masked_multivoxel(capi, orc, ctx, g2, name, pipeline):
     gt, ot = make_targets(capi, orc, ctx, g2["target"], g2["plane_normals"], float(g2["voxel_size"]))
     scan = capi.Scan(ctx, g2["source"])
     H, g, e2 = check_against(capi, orc, gt, ot, name, g2["T"], g2["source"], float(g2["max_dist"]), scan=scan)
-    # a second pass over the same scan handle at another pose (the "seeded" pipeline starts it from the
-    # first pass' matches): still exactly the oracle's sums
+    # further passes over the same scan handle at other poses (the "reuse" pipelines certify / re-search the
+    # previous pass' matches instead of searching afresh): still exactly the oracle's sums
     T2 = np.array(g2["T"]); T2[:3, 3] += [0.05, -0.03, 0.02]
     check_against(capi, orc, gt, ot, name, T2, g2["source"], float(g2["max_dist"]), scan=scan)
     check_against(capi, orc, gt, ot, name, np.eye(4), g2["source"], float(g2["max_dist"]), scan=scan)
@@ -397,9 +397,10 @@ def test_profile_counters(capi, ctx, g2, pipeline):
     ctx.profile_enable(False)
     want = {"default": dict(nn=0, reduce=0, finalize=0, linearize=5),          # a 2 k-point scan: the fused kernel
             "split": dict(nn=5, reduce=5, finalize=0, linearize=0),
-            "seeded": dict(nn=5, reduce=5, finalize=0, linearize=0),
+            "reuse": dict(nn=5, reduce=5, finalize=0, linearize=0, certify=3),     # full, tracking, 3 x certify + list
+            "noreuse": dict(nn=5, reduce=5, finalize=0, linearize=0, certify=0),
             "coop": dict(nn=5, reduce=5, finalize=0, linearize=0),
-            "unfused": dict(nn=5, reduce=5, finalize=5, linearize=0),
+            "unfused": dict(nn=5, reduce=5, finalize=5, linearize=0, certify=3),
             "onekernel": dict(nn=0, reduce=0, finalize=0, linearize=5),
             "onekernel_unfused": dict(nn=0, reduce=0, finalize=5, linearize=5)}[pipeline]
     assert {k: prof[k][0] for k in want} == want
@@ -826,3 +827,102 @@ def test_fuzz_knn(capi, orc, ctx, seed):
     do, io = orc.knn_brute(pts, q, k)
     assert np.array_equal(d, do)
     assert np.array_equal(i, io)
+
+
+# ----------------------------------------------------------------------------- certified reuse
+def _small_steps(rng, T0, n, rot, trans):
+    """A pose sequence the way a converging Gauss-Newton loop produces one: steps that shrink."""
+    from point_cloud_registration_amd.synthetic import make_T
+    out, T = [], np.array(T0, dtype=np.float64)
+    for k in range(n):
+        s = 0.5 ** k
+        T = T @ make_T(rng.normal(0, rot * s, 3), rng.normal(0, trans * s, 3))
+        out.append(T.copy())
+    return out
+
+
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("family", ["copy", "resampled", "crop"])
+def test_certified_reuse_is_exact(capi, orc, ctx, name, family):
+    """Passes that certify the previous matches (k_certify) and search only the rest return the SAME BITS as passes
+    that search everything: walk pose sequences with shrinking steps, jumps, a changed gate and (point targets) a
+    changed kind on one scan handle with reuse forced on, and compare every pass with a fresh full search.  The
+    families: a noisy copy of target points (matches at the noise level), an independent sample of the same
+    surfaces (matches at half the point spacing), a 30 %-overlap crop (most points have nothing in reach)."""
+    from point_cloud_registration_amd.synthetic import street, perturbed_scan, make_T, T_TRUE_SO3, T_TRUE_T
+    rng = np.random.default_rng(11)
+    target = street(60_000, seed=5)
+    normals = None
+    if family == "copy":
+        scan, T_true = perturbed_scan(target, 20_000, seed=6)
+    else:
+        T_true = make_T(T_TRUE_SO3, T_TRUE_T)
+        other = street(20_000 if family == "resampled" else 40_000, seed=77)
+        if family == "crop":
+            other = other[other[:, 0] > 24.0]                   # the far 30 % of the street ...
+            other[:, 0] += 30.0                                 # ... pushed so that only a 6 m strip overlaps
+        Ri = T_true[:3, :3].T
+        scan = ((Ri @ other.astype(np.float64).T).T - Ri @ T_true[:3, 3]).astype(np.float32)
+    scan[7] = np.nan                                            # a non-finite scan point never matches
+    o_vox = orc.TargetVoxels(target, 1.0)
+    if name in ("icp", "plane"):
+        tgt = capi.Target.points(ctx, target)
+        if name == "plane":
+            tgt.estimate_normals(10, want=False)
+    else:
+        tgt = capi.Target.voxels_from_stats(ctx, o_vox.mean, o_vox.norm, o_vox.icov, 1.0)
+    kind = kind_of(capi, name)
+    poses = [np.eye(4)] + _small_steps(rng, T_true, 6, 2e-3, 2e-2)
+    poses += [poses[-1], poses[-1]]                             # a repeated pose: everything certifies
+    poses += _small_steps(rng, np.eye(4), 3, 1e-4, 1e-3)        # a jump back, then small steps again
+    gates = [2.0] * len(poses)
+    gates[4] = 0.5; gates[5] = 3.0                              # the gate may change between passes
+    with ctx.pipeline(variant=1, fuse_finalize=1, nn_mode=0, reuse=0):
+        ref_scan = capi.Scan(ctx, scan)
+        ref = [capi.linearize(tgt, ref_scan, kind, T, md) for T, md in zip(poses, gates)]
+    for reuse in (2, 1):
+        with ctx.pipeline(variant=1, fuse_finalize=1, nn_mode=0, reuse=reuse):
+            sc = capi.Scan(ctx, scan)
+            for k, (T, md) in enumerate(zip(poses, gates)):
+                out = capi.linearize(tgt, sc, kind, T, md)
+                assert np.array_equal(out, ref[k]), (name, family, reuse, k, sc.reuse_stats())
+            st = sc.reuse_stats()
+        if reuse == 2:
+            assert st["passes_full"] == 1 and st["passes_track"] == 1 and st["passes_list"] == len(poses) - 2
+            assert 0 < st["list_searched"] < st["list_points"], st   # some certified, some searched
+    # the oracle agrees (the reference chain: oracle == full search == certified reuse)
+    ot = orc.TargetPoints(target, normals=tgt.get_normals() if name == "plane" else None) if name in ("icp", "plane") else o_vox
+    for k in (3, len(poses) - 1):
+        Ho, go, e2o, cnto = orc.calc_H_g_e2(kind, ot, poses[k], scan, gates[k], with_count=True)
+        H, g, e2, cnt = capi.unpack29(ref[k])
+        assert cnt == cnto and (cnt == 0 or rel_H(H, Ho) < TOL_ORC)
+    assert family == "crop" or capi.unpack29(ref[3])[3] > 100
+
+
+def test_certified_reuse_shared_point_target(capi, ctx):
+    """ICP and PlaneICP passes interleaved on ONE scan and ONE point target share the tracked matches."""
+    from point_cloud_registration_amd.synthetic import street, perturbed_scan
+    target = street(50_000, seed=8)
+    scan, T_true = perturbed_scan(target, 15_000, seed=9)
+    tgt = capi.Target.points(ctx, target)
+    tgt.estimate_normals(10, want=False)
+    rng = np.random.default_rng(3)
+    poses = _small_steps(rng, T_true, 8, 1e-3, 1e-2)
+    kinds = [capi.ICP, capi.PLANE] * 4
+    with ctx.pipeline(variant=1, reuse=0):
+        s0 = capi.Scan(ctx, scan)
+        ref = [capi.linearize(tgt, s0, k, T, 2.0) for k, T in zip(kinds, poses)]
+    with ctx.pipeline(variant=1, reuse=2):
+        s1 = capi.Scan(ctx, scan)
+        got = [capi.linearize(tgt, s1, k, T, 2.0) for k, T in zip(kinds, poses)]
+        assert s1.reuse_stats()["passes_list"] == 6
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    # another target: the scan's tracked matches are not valid for it -> a fresh full search, same bits
+    tgt2 = capi.Target.points(ctx, target[::2].copy())
+    with ctx.pipeline(variant=1, reuse=0):
+        r2 = capi.linearize(tgt2, s0, capi.ICP, poses[-1], 2.0)
+    with ctx.pipeline(variant=1, reuse=2):
+        g2_ = capi.linearize(tgt2, s1, capi.ICP, poses[-1], 2.0)
+        assert s1.reuse_stats()["last_mode"] == capi.NN_FULL
+    assert np.array_equal(r2, g2_)
