@@ -348,6 +348,8 @@ def main():
                                               "kernel_ms": round(kern["reduce"]["avg_ms"], 5)}
         if per_rank is not None:
             line["per_rank_kernel_ms"] = per_rank
+        if world == 1:
+            line["seam"] = seam_timings(kind_name, target, scan, tgt, sc, kind, traj, max_dist, voxel_size, n_target)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(kind_name, target, scan, tgt, traj, max_dist, voxel_size,
                                                 args.cpu_passes)
@@ -357,6 +359,58 @@ def main():
         torch.distributed.barrier()
         comm.close()
         torch.distributed.destroy_process_group()
+
+
+def seam_timings(kind_name, target, scan, tgt, sc, kind, traj, max_dist, voxel_size, n_target):
+    """Beside the C-ABI headline: the same pass through the reference-shaped CLASS seam (S1, registration.py:55-68:
+    ``calc_H_g_e2(cur_T, source)`` with the scan as a host array -- content hash per call -- and with an uploaded
+    handle), and whole ``align()`` calls (``set_target`` excluded): behind the C ABI on the resident scan, and
+    through the class from the host array (upload + Morton sort included).  Not part of ``value``."""
+    import gc
+    import point_cloud_registration_amd as pcr
+    from point_cloud_registration_amd import _capi
+    out = {}
+    reps = 3
+    ts = []
+    for _ in range(reps + 1):
+        t0 = time.perf_counter()
+        T, it = _capi.align(tgt, sc, kind, np.eye(4), 30, 1e-3, max_dist)
+        ts.append(time.perf_counter() - t0)
+    out["align_ms"] = round(float(np.median(ts[1:])) * 1e3, 4)
+    out["align_iterations"] = int(it)
+    if n_target > 20_000_000:
+        out["note"] = "class seam not timed at this size (it would rebuild the 1e8-point target)"
+        return out
+    cls = {"icp": lambda: pcr.ICP(max_dist=max_dist), "plane": lambda: pcr.PlaneICP(max_dist=max_dist, k=15),
+           "vplane": lambda: pcr.VPlaneICP(voxel_size=voxel_size, max_dist=max_dist),
+           "ndt": lambda: pcr.NDT(voxel_size=voxel_size, max_dist=max_dist)}[kind_name]()
+    t0 = time.perf_counter()
+    cls.set_target(target)
+    out["set_target_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+    n = max(3 * len(traj), 15)
+    gc.collect(); gc.disable()
+    try:
+        for form in ("array", "handle"):
+            src = scan if form == "array" else cls.upload(scan)
+            for k in range(len(traj)):
+                cls.calc_H_g_e2(traj[k], src)
+            t0 = time.perf_counter()
+            for k in range(n):
+                cls.calc_H_g_e2(traj[k % len(traj)], src)
+            out[f"calc_H_g_e2_{form}_ms_per_call"] = round((time.perf_counter() - t0) / n * 1e3, 4)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            _capi.hash64(scan)
+        out["content_hash_ms"] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
+        ts = []
+        for _ in range(reps + 1):
+            t0 = time.perf_counter()
+            cls.align(scan)
+            ts.append(time.perf_counter() - t0)
+        out["class_align_from_host_array_ms"] = round(float(np.median(ts[1:])) * 1e3, 4)
+    finally:
+        gc.enable()
+    return out
 
 
 def cpu_baseline(kind_name, target, scan, gpu_target, traj, max_dist, voxel_size, passes):

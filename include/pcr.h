@@ -134,6 +134,12 @@ PCR_API pcr_status pcr_scan_create_device(pcr_context *ctx, const float *d_xyz, 
 PCR_API pcr_status pcr_scan_size(pcr_scan *s, int64_t *n);
 PCR_API pcr_status pcr_scan_destroy(pcr_scan *s);
 
+/* calc_H_g_e2(cur_T, source) takes the scan as an array on every call and is pure in it (registration.py:55-68):
+ * the drop-in class keeps the device copy of the last scan and re-uploads when the CONTENT of the caller's array
+ * changed.  pcr_hash64 is the content hash it uses: 64-bit, non-cryptographic, multi-threaded (12.7 MB in ~0.1 ms
+ * on the GPU box's host; the value does not depend on the number of threads).                               */
+PCR_API pcr_status pcr_hash64(const void *data, uint64_t nbytes, uint64_t *out);
+
 /* ---- the hot path ---------------------------------------------------------------------
  * One calc_H_g_e2: transform (math_tools.py:111-113) -> exact 1-NN (kdtree.py:18-21 /
  * voxel.py:171-179) -> gate dist < max_dist -> residual + Jacobian -> 6x6 normal equations
@@ -146,8 +152,8 @@ PCR_API pcr_status pcr_linearize(pcr_target *t, pcr_scan *s, int kind, const dou
 /* Registration.align (registration.py:71-113) run entirely behind the boundary: up to
  * max_iter x { pcr_linearize, dx = -solve(H, g), stop if |dx| < tol (before the update,
  * quirk Q4), T <- plus(T, dx) (math_tools.py:101-108, first-order expSO3 branch, quirk Q3) }.
- * The loop is device-resident: the pose stays in HBM, the 6x6 solve and the update run in the
- * last block of the reduce kernel, iterations are enqueued back to back and the host reads one
+ * The loop is device-resident: the pose stays in HBM, the 6x6 solve and the update run in a one-wave
+ * kernel (k_gn_update) behind the reduce kernel, iterations are enqueued back to back and the host reads one
  * result (PCR_FLAG_HOST_LOOP selects the host-driven form of the same arithmetic).
  * trace_or_null receives up to max_iter rows of 16 (T before the step) + 29 doubles.
  * Returns PCR_ERR_SINGULAR where numpy.linalg.solve would raise LinAlgError (quirk Q7).     */

@@ -82,6 +82,7 @@ PROTOTYPES = {
     "pcr_set_reuse": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double]),
     "pcr_get_reuse": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pcr_scan_reuse_stats": (C.c_int, [_vp, _f64p]),
+    "pcr_hash64": (C.c_int, [_vp, C.c_uint64, C.POINTER(C.c_uint64)]),
 }
 
 
@@ -474,6 +475,13 @@ class Scan:
             self.close()
         except Exception:
             pass
+
+
+def hash64(arr):
+    """Content hash of a C-contiguous NumPy array's buffer (pcr_hash64: multi-threaded, 64 bits)."""
+    h = C.c_uint64(0)
+    check(lib().pcr_hash64(arr.ctypes.data_as(_vp), arr.nbytes, C.byref(h)))
+    return h.value
 
 
 def linearize(target, scan, kind, T, max_dist, flags=FLAG_ICP_RR_QUIRK):

@@ -74,6 +74,16 @@ void pcr_cache_clear(pcr_context *ctx) {
     ctx->cache_bytes = 0;
 }
 
+hipError_t pcr_malloc_retry(void **p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess && pcr_tls_ctx && !pcr_tls_ctx->cache.empty()) {
+        (void)hipGetLastError();
+        pcr_cache_clear(pcr_tls_ctx);
+        e = hipMalloc(p, bytes);
+    }
+    return e;
+}
+
 // ---- context --------------------------------------------------------------------------------
 extern "C" pcr_status pcr_context_create(int device, pcr_context **out) {
     PCR_REQUIRE(out, "out is NULL");
@@ -315,7 +325,7 @@ static pcr_status points_create_common(pcr_context *ctx, const float *d_xyz, int
     t->ctx = ctx; t->is_voxel = 0; t->n = n; t->serial = ctx->next_serial++;
     pcr_status s = pcr_build_point_grid(ctx, d_xyz, n, cell_hint, t);
     if (s == PCR_OK && d_normals) {
-        hipError_t e = hipMalloc(&t->pn, sizeof(PtN) * (size_t)(n ? n : 1));
+        hipError_t e = pcr_malloc_retry((void **)&t->pn, sizeof(PtN) * (size_t)(n ? n : 1));
         if (e != hipSuccess) { pcr_set_error("hipMalloc normals: %s", hipGetErrorString(e)); s = PCR_ERR_HIP; }
         else s = pcr_permute_normals(ctx, d_normals, n, t->pts, t->pn);
         if (s == PCR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s = PCR_ERR_HIP;
@@ -355,7 +365,7 @@ extern "C" pcr_status pcr_target_set_normals(pcr_target *t, const float *normals
     CtxScope scope(ctx);
     DevBuf<float> d_nrm;
     PCR_TRY(upload<float>(ctx, normals, (size_t)t->n * 3, &d_nrm));
-    if (!t->pn) HIP_TRY(hipMalloc(&t->pn, sizeof(PtN) * (size_t)(t->n ? t->n : 1)));
+    if (!t->pn) HIP_TRY(pcr_malloc_retry((void **)&t->pn, sizeof(PtN) * (size_t)(t->n ? t->n : 1)));
     PCR_TRY(pcr_permute_normals(ctx, d_nrm.p, t->n, t->pts, t->pn));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PCR_OK;
@@ -394,12 +404,12 @@ pcr_status pcr_voxel_target_finish(pcr_context *ctx, pcr_target *t, double voxel
     PCR_TRY(pcr_build_centroid_grid(ctx, t->st_mean, t->n, voxel_size, t));
     const size_t nn = (size_t)(t->n ? t->n : 1);
     if (t->st_norm) {
-        HIP_TRY(hipMalloc(&t->vnorm, sizeof(double) * 3 * nn));
+        HIP_TRY(pcr_malloc_retry((void **)&t->vnorm, sizeof(double) * 3 * nn));
         const int cols[3] = {0, 1, 2};
         PCR_TRY(pcr_permute_rows_f64(ctx, t->st_norm, t->n, 3, cols, 3, t->means, t->vnorm));
     }
     if (t->st_icov) {
-        HIP_TRY(hipMalloc(&t->vicov, sizeof(double) * 6 * nn));
+        HIP_TRY(pcr_malloc_retry((void **)&t->vicov, sizeof(double) * 6 * nn));
         const int cols[6] = {0, 1, 2, 4, 5, 8};
         PCR_TRY(pcr_permute_rows_f64(ctx, t->st_icov, t->n, 9, cols, 6, t->means, t->vicov));
     }
@@ -530,6 +540,7 @@ extern "C" pcr_status pcr_scan_destroy(pcr_scan *s) {
 extern "C" pcr_status pcr_linearize(pcr_target *t, pcr_scan *s, int kind, const double T[16], double max_dist,
                                     unsigned flags, double out[29]) {
     PCR_REQUIRE(t && s && T && out, "NULL argument");
+    CtxScope scope(t->ctx);
     return pcr_run_linearize(t, s, kind, T, max_dist, flags, out);
 }
 
@@ -568,6 +579,7 @@ extern "C" pcr_status pcr_align(pcr_target *t, pcr_scan *s, int kind, const doub
                                 double max_dist, unsigned flags, double T_out[16], int *iterations,
                                 double *trace_or_null) {
     PCR_REQUIRE(t && s && T_init && T_out, "NULL argument");
+    CtxScope scope(t->ctx);
     // (certified reuse runs on host-driven passes; forced on, the loop is driven from the host)
     if ((flags & PCR_FLAG_HOST_LOOP) || t->ctx->reuse == 2)
         return align_host_loop(t, s, kind, T_init, max_iter, tol, max_dist, flags, T_out, iterations, trace_or_null);

@@ -1,5 +1,5 @@
-// The O(1) tail of a Gauss-Newton iteration, shared by the host driver (api.hip) and the last block
-// of the reduce kernel (kernels.hip): dx = -solve(H, g), the |dx| < tol test, T <- plus(T, dx).
+// The O(1) tail of a Gauss-Newton iteration, shared by the host driver (api.hip) and the one-wave kernel
+// k_gn_update (kernels.hip): dx = -solve(H, g), the |dx| < tol test, T <- plus(T, dx).
 // Reference: registration.py:103-111 (loop body), math_tools.py:80-108 (expSO3, plus).
 #pragma once
 

@@ -83,9 +83,9 @@ __device__ __forceinline__ double uniform_f64(double v) {
 }
 
 // The pose of this launch, in scalar registers.  Returns false when the device-resident loop has
-// already finished (nothing to do).  Every block reads the pose before it contributes to the
-// reduction, and the pose is rewritten only by the block that folds the LAST contribution, so a
-// read never races with the update; across launches the kernel boundary orders them.
+// already finished (nothing to do).  Every block reads the pose at its start; the pose is rewritten
+// only by k_gn_update, a separate launch on the same stream behind the reduce kernel, so a read never
+// races with the update: the kernel boundary orders them.
 template <bool NEED_R>
 __device__ __forceinline__ bool load_pose(const LinArgs &a, PoseK &P) {
     if (a.pose == nullptr) { P = a.hp; return true; }
@@ -1259,16 +1259,16 @@ pcr_status pcr_ensure_scratch(pcr_context *ctx, int64_t n_points) {
     if (!ctx->d_partials) {
         ctx->max_blocks = (ctx->num_cu * 16 + 7) & ~7;
         // + 8 rows: the group sums of k_reduce_finalize live behind the per-block rows
-        HIP_TRY(hipMalloc(&ctx->d_partials, sizeof(double) * 32 * (size_t)(ctx->max_blocks + 8)));
-        HIP_TRY(hipMalloc(&ctx->d_out, sizeof(double) * 32));
-        HIP_TRY(hipMalloc(&ctx->d_pose, sizeof(PoseDev)));
+        HIP_TRY(pcr_malloc_retry((void **)&ctx->d_partials, sizeof(double) * 32 * (size_t)(ctx->max_blocks + 8)));
+        HIP_TRY(pcr_malloc_retry((void **)&ctx->d_out, sizeof(double) * 32));
+        HIP_TRY(pcr_malloc_retry((void **)&ctx->d_pose, sizeof(PoseDev)));
         // pinned + mapped: [0..28] sums, [32] sequence number (pcr_linearize); [40..55] pose, [56] loop state (pcr_align)
         HIP_TRY(hipHostMalloc(&ctx->h_out, sizeof(double) * 64, hipHostMallocMapped | hipHostMallocCoherent));
         memset(ctx->h_out, 0, sizeof(double) * 64);
         HIP_TRY(hipHostGetDevicePointer((void **)&ctx->h_out_dev, ctx->h_out, 0));
         // 8 + 1 tickets (64 B apart), then the tile counters
         const size_t ctr_words = 9 * 16 + (size_t)PCR_TILE_CTRS * PCR_TILE_STRIDE;
-        HIP_TRY(hipMalloc(&ctx->d_tile_ctr, sizeof(uint32_t) * ctr_words));
+        HIP_TRY(pcr_malloc_retry((void **)&ctx->d_tile_ctr, sizeof(uint32_t) * ctr_words));
         HIP_TRY(hipMemsetAsync(ctx->d_tile_ctr, 0, sizeof(uint32_t) * ctr_words, ctx->stream));
         for (int v = 0; v < 3; ++v) {
             int nb = 0;
@@ -1331,7 +1331,7 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
     bool one_kernel = ctx->variant == 0;
     if (ctx->variant == 2) one_kernel = s->n <= (int64_t)ctx->num_cu * 1024;   // measured crossover: 200 k - 300 k points on 256 CUs
     if (!one_kernel && !s->nn_j) {
-        HIP_TRY(hipMalloc(&s->nn_j, sizeof(uint32_t) * (size_t)(s->n > 0 ? s->n : 1)));
+        HIP_TRY(pcr_malloc_retry((void **)&s->nn_j, sizeof(uint32_t) * (size_t)(s->n > 0 ? s->n : 1)));
         s->nn_serial = 0;
     }
     const int nblocks_split = [&] {
@@ -1344,15 +1344,15 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
     if (!one_kernel && ctx->reuse != 0 && ctx->nn_mode == 0 && s->n > 0) {
         if (!s->lb2) {
             const size_t words = (((size_t)s->n + 63) / 64 + 31) & ~(size_t)15;     // whole 16-word chunks + slack
-            HIP_TRY(hipMalloc(&s->lb2, sizeof(float) * (size_t)s->n));
-            HIP_TRY(hipMalloc(&s->umask, sizeof(unsigned long long) * words));
+            HIP_TRY(pcr_malloc_retry((void **)&s->lb2, sizeof(float) * (size_t)s->n));
+            HIP_TRY(pcr_malloc_retry((void **)&s->umask, sizeof(unsigned long long) * words));
             HIP_TRY(hipMemsetAsync(s->umask, 0, sizeof(unsigned long long) * words, ctx->stream));
             s->track_valid = false;
         }
         if (s->ucnt_cap < nblocks_split) {
             if (s->ucnt) HIP_TRY(hipFree(s->ucnt));
             s->ucnt = nullptr; s->ucnt_cap = 0;
-            HIP_TRY(hipMalloc(&s->ucnt, sizeof(uint32_t) * (size_t)nblocks_split));
+            HIP_TRY(pcr_malloc_retry((void **)&s->ucnt, sizeof(uint32_t) * (size_t)nblocks_split));
             s->ucnt_cap = nblocks_split;
         }
         ps->reuse_ready = true;
@@ -1622,7 +1622,7 @@ pcr_status pcr_run_align(pcr_target *t, pcr_scan *s, int kind, const double T_in
     if (ctx->trace_cap < max_iter) {
         if (ctx->d_trace) HIP_TRY(hipFree(ctx->d_trace));
         ctx->d_trace = nullptr; ctx->trace_cap = 0;
-        HIP_TRY(hipMalloc(&ctx->d_trace, sizeof(double) * 45 * (size_t)max_iter));
+        HIP_TRY(pcr_malloc_retry((void **)&ctx->d_trace, sizeof(double) * 45 * (size_t)max_iter));
         ctx->trace_cap = max_iter;
     }
     const bool use_comm = ctx->comm != nullptr && !(flags & PCR_FLAG_LOCAL_ONLY);
@@ -1704,6 +1704,7 @@ pcr_status pcr_run_nn(pcr_target *t, const float *d_q, int64_t m, double r_max, 
     const dim3 grid((unsigned)((m + 255) / 256)), block(256);
     const bool bounded = r_max > 0 && r_max < 1e300 * 1e300;
     ProfEvent ev;
+    ctx->prof_this_pass = ctx->prof_on;            // (pass sampling applies to passes only)
     pcr_prof_begin(ctx, PCR_K_NN, &ev);
     if (!f64) {
         PCR_REQUIRE(!t->is_voxel, "pcr_nn_query needs a point target (use pcr_nn_query_f64 for voxels)");

@@ -74,7 +74,7 @@ struct __attribute__((aligned(32))) PtN {
 };
 
 // Device-resident state of the Gauss-Newton loop (pcr_align): the pose every kernel of an iteration
-// reads, rewritten by the last block of the reduce kernel (solve + boxplus on the device).
+// reads, rewritten by k_gn_update (solve + boxplus on the device, one wave, its own launch).
 struct PoseDev {
     double T[16];          // current pose, row-major
     double R[9];           // = T[:3,:3]
@@ -99,6 +99,8 @@ void *pcr_cache_get(pcr_context *ctx, size_t bytes, size_t *cap_out);     // nul
 void pcr_cache_put(pcr_context *ctx, void *p, size_t cap);
 void pcr_cache_clear(pcr_context *ctx);
 extern thread_local pcr_context *pcr_tls_ctx;
+// hipMalloc; on failure the current context's idle blocks (up to 1 GiB) are released and the call is retried once
+hipError_t pcr_malloc_retry(void **p, size_t bytes);
 struct CtxScope {
     pcr_context *prev;
     explicit CtxScope(pcr_context *ctx) : prev(pcr_tls_ctx) { pcr_tls_ctx = ctx; }
@@ -122,7 +124,7 @@ struct DevBuf {
         reset();
         owner = nullptr;
         cap = sizeof(T) * (count ? count : 1);
-        const hipError_t e = hipMalloc(&p, cap);
+        const hipError_t e = pcr_malloc_retry((void **)&p, cap);
         if (e != hipSuccess) { p = nullptr; cap = 0; }
         return e;
     }
@@ -136,7 +138,7 @@ struct DevBuf {
             bytes = (bytes + 4095) & ~(size_t)4095;
         }
         cap = bytes;
-        const hipError_t e = hipMalloc(&p, bytes);
+        const hipError_t e = pcr_malloc_retry((void **)&p, bytes);
         if (e != hipSuccess) { p = nullptr; cap = 0; }
         return e;
     }

@@ -11,24 +11,31 @@ Additions (none changes a default):
 * ``device=`` -- which GPU this process drives (default ``LOCAL_RANK``);
 * ``comm=`` -- a :class:`distributed.Communicator`; the scan passed to ``align`` is then this
   rank's SHARD and every ``calc_H_g_e2`` returns the sum over all ranks (SURVEY.md section 8e);
+* ``upload(source)`` -- returns a handle to the device copy of a scan; ``calc_H_g_e2(cur_T, handle)`` and
+  ``align(handle)`` then skip the upload and the per-call content hash of the array form;
 * ``native_loop`` (default True) -- ``align`` runs the whole loop behind the C ABI (``pcr_align``):
-  pose in HBM, solve + boxplus in the last block of the reduce kernel, iterations enqueued back to
+  pose in HBM, solve + boxplus in a one-wave kernel behind the reduce kernel, iterations enqueued back to
   back, one result read by the host.  ``native_loop=False`` keeps the Python loop of the reference
   (one ``calc_H_g_e2`` + ``numpy.linalg.solve`` per iteration), which ``verbose=True`` also uses
   (it prints the reference's line before every solve).
 """
 
-import zlib
-
 import numpy as np
-
-try:                                   # fast non-cryptographic hash of the scan buffer (see _scan_for)
-    import xxhash as _xxhash
-except ImportError:                    # pragma: no cover
-    _xxhash = None
 
 from . import _capi
 from .math_tools import plus
+
+
+class UploadedScan:
+    """A scan that already lives on the GPU (``Registration.upload``): pass it wherever ``source`` is expected
+    to skip the per-call content hash of the array form."""
+
+    def __init__(self, scan, shape):
+        self._scan = scan
+        self.shape = shape
+
+    def close(self):
+        self._scan.close()
 
 
 class Registration:
@@ -72,11 +79,19 @@ class Registration:
         scan = self._scan_for(source)
         return self._linearize(np.asarray(cur_T, dtype=np.float64), scan)
 
+    def upload(self, source):
+        """Upload (and Morton-sort) ``source`` once; the returned handle can stand in for the array in
+        ``calc_H_g_e2`` / ``align`` (the caller then owns the "has it changed?" question)."""
+        src = np.asarray(source)
+        if src.ndim != 2 or src.shape[1] != 3:
+            raise ValueError("source must have shape (N, 3)")
+        return UploadedScan(_capi.Scan(self._ctx(), src.astype(np.float32, copy=False)), src.shape)
+
     def align(self, source, init_T=np.eye(4), verbose=False):
         """Gauss-Newton alignment of ``source`` onto the target; returns the 4x4 float64 pose."""
         if self.is_target_set() is False:
             raise ValueError("Target is not set.")
-        scan = self._scan_for(np.asarray(source), fresh=True)     # the reference copies the scan per call
+        scan = self._scan_for(source, fresh=True)     # the reference copies the scan per call
         cur_T = np.array(init_T, dtype=np.float64)
         if self._native_loop and not verbose and not self._needs_host_reduce():
             T, iters, trace = _capi.align(self._target, scan, self.KIND, cur_T, self.max_iter, self.tol,
@@ -118,14 +133,11 @@ class Registration:
 
     @staticmethod
     def _digest(src):
-        """Hash of the WHOLE scan buffer (xxh3: ~1 ms per 1e6 float32 points; crc32 otherwise)."""
+        """64-bit hash of the WHOLE scan buffer (``pcr_hash64`` inside libpcr_hip.so: multi-threaded, ~0.1 ms per
+        1e6 float32 points on the GPU box's host; no optional Python dependency)."""
         if src.size == 0:
             return 0
-        buf = src if src.flags.c_contiguous else np.ascontiguousarray(src)
-        mv = memoryview(buf).cast("B")
-        if _xxhash is not None:
-            return _xxhash.xxh3_64_intdigest(mv)
-        return zlib.crc32(mv)
+        return _capi.hash64(src if src.flags.c_contiguous else np.ascontiguousarray(src))
 
     def _scan_for(self, source, fresh=False):
         """Upload (and Morton-sort) the scan; ``calc_H_g_e2`` called repeatedly with the same array
@@ -133,6 +145,8 @@ class Registration:
         the whole buffer is hashed on every call, so an in-place edit is always seen
         (``calc_H_g_e2`` stays pure in its inputs, as in the reference); ``align`` always uploads
         afresh."""
+        if isinstance(source, UploadedScan):
+            return source._scan
         src = np.asarray(source)
         if src.ndim != 2 or src.shape[1] != 3:
             raise ValueError("source must have shape (N, 3)")

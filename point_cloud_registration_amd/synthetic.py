@@ -54,6 +54,25 @@ def street(n, seed=0, center=(0.0, 0.0)):
     return pts.astype(np.float32)
 
 
+def street_normals(pts, center=(0.0, 0.0)):
+    """Analytic unit normals of a ``street`` cloud, from the coordinates alone: the first half of the points
+    are the ground (0, 0, 1); of the next 40 % those within 0.2 m of y = +-30 belong to the y-walls (0, 1, 0),
+    the others to the x-walls (1, 0, 0); the clutter gets (0, 0, 1).  A reproducible, geometrically meaningful
+    input for ``PlaneICP.set_target(target, tree, norm)`` (plane_icp.py:25-27) that does not depend on any
+    normal estimator."""
+    n = pts.shape[0]
+    n_ground = n // 2
+    n_wall = (n * 4) // 10
+    out = np.zeros((n, 3), dtype=np.float32)
+    out[:, 2] = 1.0
+    w = slice(n_ground, n_ground + n_wall)
+    ywall = np.abs(np.abs(pts[w, 1] - np.float32(center[1])) - 30.0) < 0.2
+    out[w, 2] = 0.0
+    out[w, 1] = ywall
+    out[w, 0] = ~ywall
+    return out
+
+
 def street_tiled(n_total, seed=0, per_tile=1_000_000):
     """Constant-density large cloud: tiles of the 120 x 60 m street on a near-square grid
     with per-tile seeds, mean-centred."""

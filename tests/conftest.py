@@ -55,6 +55,28 @@ def g7():
     return g
 
 
+@pytest.fixture(scope="session")
+def g9():
+    return load_golden("g9_q6_f64_target.npz")
+
+
+@pytest.fixture(scope="session")
+def g8():
+    """BASELINE-size fixture (reference run on the 1.06 M-point B-01 stand-in) + the clouds it refers to,
+    regenerated from the deterministic generators and checksum-guarded."""
+    import zlib
+    from point_cloud_registration_amd.synthetic import street, harness_scan, perturbed_scan, street_normals
+    g = load_golden("g8_b01_fullsize.npz")
+    target = street(int(g["n"]), seed=0)
+    clouds = {"target": target, "harness100k": harness_scan(target, 100_000, seed=1),
+              "pert100k": perturbed_scan(target, 100_000, seed=2)[0],
+              "pertfull": perturbed_scan(target, None, seed=2)[0], "given_normals": street_normals(target)}
+    for name, arr in clouds.items():
+        assert zlib.crc32(arr.tobytes()) == int(g[f"crc32_{name}"]), f"{name}: the generator no longer reproduces the fixture's cloud"
+    g.update(clouds)
+    return g
+
+
 def rel_H(H, Href):
     """Parity metric of SURVEY.md section 8a Q5: max|dH| / max|H_ref|."""
     return float(np.max(np.abs(np.asarray(H) - np.asarray(Href))) / np.max(np.abs(Href)))

@@ -242,10 +242,99 @@ def g7():
     np.savez_compressed(os.path.join(HERE, "g7_normals_fullscale.npz"), **out)
 
 
+def g9():
+    """Quirk Q6: PlaneICP builds its tree on the ORIGINAL-dtype array (plane_icp.py:22) and gathers from the float32
+    copy (plane_icp.py:20,44).  A float64 target whose coordinates are not float32-representable: the reference's
+    H, g, e2 (float64 tree) and, for the record, how many neighbours differ from a float32 tree's."""
+    base = mini_street(5000, seed=13).astype(np.float64)
+    rng = np.random.default_rng(5)
+    target = base + rng.uniform(-3e-8, 3e-8, base.shape)          # below float32 resolution at these magnitudes
+    assert not np.array_equal(target, target.astype(np.float32).astype(np.float64))
+    pick = rng.choice(target.shape[0], 2000, replace=False)
+    T = non_identity_T()
+    Rinv = T[:3, :3].T
+    scan = ((Rinv @ target[pick].T).T - Rinv @ T[:3, 3] + rng.normal(0, 0.002, (2000, 3))).astype(np.float32)
+    picp = ref.PlaneICP(max_dist=0.8, k=10)
+    picp.set_target(target)
+    out = {"target": target, "source": scan, "T": T, "max_dist": 0.8, "k": 10, "plane_normals": np.asarray(picp.normal)}
+    out["T_plane_H"], out["T_plane_g"], out["T_plane_e2"] = triple(picp.calc_H_g_e2(T, scan))
+    out["I_plane_H"], out["I_plane_g"], out["I_plane_e2"] = triple(picp.calc_H_g_e2(np.eye(4), scan))
+    st = ref.transform_points(T.astype(np.float32), scan)
+    d64, i64 = picp.kdtree.query(st)
+    t32 = ref.KDTree(target.astype(np.float32))
+    d32, i32 = t32.query(st)
+    out["nn_idx_f64_tree"], out["nn_idx_f32_tree"] = i64, i32
+    out["align_final"] = picp.align(scan, np.eye(4))
+    print("G9 (Q6): neighbours that differ between the float64 and the float32 tree:", int(np.sum(i64 != i32)), "of", len(i64))
+    np.savez_compressed(os.path.join(HERE, "g9_q6_f64_target.npz"), **out)
+
+
+def _traj(obj, scan):
+    """The reference's align() loop (registration.py:89-111) unrolled to record every iterate."""
+    cur = np.eye(4)
+    Ts, Hs, gs, e2s = [], [], [], []
+    src32 = scan.astype(np.float32)
+    for _ in range(obj.max_iter):
+        H, g, e2 = triple(obj.calc_H_g_e2(cur, src32))
+        Ts.append(cur.copy()); Hs.append(H); gs.append(g); e2s.append(e2)
+        dx = -np.linalg.solve(H, g)
+        if np.linalg.norm(dx) < obj.tol:
+            break
+        cur = ref.plus(cur, dx)
+    final = obj.align(scan, np.eye(4))
+    assert np.allclose(final, cur, rtol=0, atol=1e-12)
+    return np.array(Ts), np.array(Hs), np.array(gs), np.array(e2s), final
+
+
+def g8():
+    """The BASELINE-size case: target = the B-01 stand-in street(1_060_000, seed=0), scans =
+    the reference harness' 100 k scan (benchmark/test_data.py:21-44: shift (0, 0, 0.3) + N(0, 0.005)), the 100 k
+    perturbed scan and the FULL 1.06 M perturbed scan; the four classes with the harness' parameters
+    (benchmark/speed_test_comparison.py:166-170: max_iter 30, tol 1e-3, max_dist 2, voxel_size 1, k 15).
+    Stored: H, g, e2 at EVERY iterate of align() (the first is the identity, the others are mid poses), every
+    cur_T, the final pose.  PlaneICP twice: with the reference's own k = 15 normals ("plane") and with supplied
+    analytic normals ("planeg", plane_icp.py:25-27) that the tests can regenerate bit for bit.  Clouds are
+    regenerated by the tests from the deterministic generators (checksums guard that)."""
+    import time
+    import zlib
+    from point_cloud_registration_amd.synthetic import harness_scan, perturbed_scan, street_normals
+    target = street(1_060_000, seed=0)
+    scans = {"harness100k": harness_scan(target, 100_000, seed=1),
+             "pert100k": perturbed_scan(target, 100_000, seed=2)[0],
+             "pertfull": perturbed_scan(target, None, seed=2)[0]}
+    out = {"n": np.int64(target.shape[0]), "crc32_target": np.int64(zlib.crc32(target.tobytes())),
+           "max_dist": 2.0, "voxel_size": 1.0, "k": 15}
+    for name, sc in scans.items():
+        out[f"crc32_{name}"] = np.int64(zlib.crc32(sc.tobytes()))
+    given = street_normals(target)
+    out["crc32_given_normals"] = np.int64(zlib.crc32(given.tobytes()))
+    t0 = time.time()
+    icp = ref.ICP(max_dist=2.0); icp.set_target(target)
+    picp = ref.PlaneICP(max_dist=2.0, k=15); picp.set_target(target)
+    out["plane_normals_sample_idx"] = np.arange(0, target.shape[0], 53, dtype=np.int64)
+    out["plane_normals_sample"] = np.asarray(picp.normal)[::53].astype(np.float32)
+    pg = ref.PlaneICP(max_dist=2.0, k=15); pg.set_target(target, picp.kdtree, given)
+    vp = ref.VPlaneICP(voxel_size=1.0, max_dist=2.0); vp.set_target(target)
+    ndt = ref.NDT(voxel_size=1.0, max_dist=2.0); ndt.set_target(target)
+    out["n_voxels"] = np.int64(vp.voxels.mean.shape[0])
+    print(f"G8 set_target x5: {time.time() - t0:.1f} s, {vp.voxels.mean.shape[0]} voxels kept", flush=True)
+    classes = {"icp": icp, "plane": picp, "planeg": pg, "vplane": vp, "ndt": ndt}
+    for sname, sc in scans.items():
+        for cname, obj in classes.items():
+            if sname == "pertfull" and cname in ("vplane", "ndt"):
+                continue
+            t0 = time.time()
+            Ts, Hs, gs, e2s, final = _traj(obj, sc)
+            tag = f"{sname}_{cname}"
+            out[f"{tag}_T"], out[f"{tag}_H"], out[f"{tag}_g"], out[f"{tag}_e2"], out[f"{tag}_final"] = Ts, Hs, gs, e2s, final
+            print(f"G8 {tag}: {len(Ts)} iterations in {time.time() - t0:.1f} s, t = {final[:3, 3]}", flush=True)
+    np.savez_compressed(os.path.join(HERE, "g8_b01_fullsize.npz"), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:
         for name in sys.argv[1:]:
             globals()[name]()
     else:
-        g1(); g2(); g3(); g5(); g6(); g7()
+        g1(); g2(); g3(); g5(); g6(); g7(); g8(); g9()
     print("done")

@@ -221,3 +221,59 @@ def test_100m_plane(capi, orc):
     T, iters = capi.align(tgt, sc_full, capi.PLANE, np.eye(4), 60, 1e-3, md)
     dt, dang = pose_err(T, T_true)
     assert dt < 2e-3 and dang < 1e-5, (dt, dang, iters)
+
+
+# ----------------------------------------------------------------------------- g8: the reference itself at B-01 size
+def _pose_err(T, ref):
+    dR = T[:3, :3] @ ref[:3, :3].T
+    ang = np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))
+    return float(np.max(np.abs(T[:3, 3] - ref[:3, 3]))), float(ang)
+
+
+@pytest.fixture(scope="module")
+def g8_targets(capi, g8):
+    """The five set_target()s of the fixture on the GPU: ICP, PlaneICP with the GPU's own k = 15 normals (the
+    reference's float32 single-pass covariance kept), PlaneICP with the supplied analytic normals, and the GPU's own
+    voxel build for VPlaneICP / NDT."""
+    ctx = capi.get_context(0)
+    target = g8["target"]
+    own = capi.Target.points(ctx, target)
+    normals = own.estimate_normals(int(g8["k"]), compat=True)
+    given = capi.Target.points(ctx, target, g8["given_normals"])
+    vox = capi.Target.voxels(ctx, target, float(g8["voxel_size"]), 10)
+    assert vox.size() == int(g8["n_voxels"])
+    # the GPU's normals against the reference's own (every 53rd point): same direction up to the sign
+    dots = np.abs(np.sum(normals[g8["plane_normals_sample_idx"]] * g8["plane_normals_sample"], axis=1))
+    assert np.mean(dots > 0.999) > 0.999
+    return {"icp": (capi.ICP, own), "plane": (capi.PLANE, own), "planeg": (capi.PLANE, given),
+            "vplane": (capi.VPLANE, vox), "ndt": (capi.NDT, vox)}
+
+
+@pytest.mark.parametrize("scan_name", ["harness100k", "pert100k", "pertfull"])
+def test_g8_hip_matches_reference_at_b01_size(capi, g8, g8_targets, scan_name):
+    """HIP against fixtures the REFERENCE produced on the 1.06 M-point B-01 stand-in -- the harness'
+    100 k scan, the 100 k perturbed scan and the full 1.06 M perturbed scan: per-iteration H within 1e-5 relative
+    (max|dH| / max|H|) at the identity and at every mid pose of the reference's align(), the same number of
+    Gauss-Newton iterations from the device-resident loop, recovered SE(3) within 1e-4 m / 1e-4 rad."""
+    ctx = capi.get_context(0)
+    scan = g8[scan_name]
+    md = float(g8["max_dist"])
+    sc = capi.Scan(ctx, scan)
+    worst = {}
+    for cname, (kind, tgt) in g8_targets.items():
+        tag = f"{scan_name}_{cname}"
+        if f"{tag}_T" not in g8:
+            continue
+        Ts = g8[f"{tag}_T"]
+        for k in range(Ts.shape[0]):
+            H, g, e2, cnt = capi.unpack29(capi.linearize(tgt, sc, kind, Ts[k], md))
+            r = rel_H(H, g8[f"{tag}_H"][k])
+            worst[cname] = max(worst.get(cname, 0.0), r)
+            assert r <= 1e-5, (tag, k, r)
+            assert np.max(np.abs(g - g8[f"{tag}_g"][k])) <= 1e-4 * np.max(np.abs(g8[f"{tag}_g"][0])), (tag, k)
+            assert abs(e2 - g8[f"{tag}_e2"][k]) <= 1e-4 * abs(g8[f"{tag}_e2"][k]), (tag, k)
+        T, iters = capi.align(tgt, sc, kind, np.eye(4), 30, 1e-3, md)
+        assert iters == Ts.shape[0], (tag, iters, Ts.shape[0])
+        dt, dr = _pose_err(T, g8[f"{tag}_final"])
+        assert dt <= 1e-4 and dr <= 1e-4, (tag, dt, dr)
+    print(f"g8 {scan_name}: worst max|dH|/max|H| vs the reference", {k: f"{v:.1e}" for k, v in worst.items()})

@@ -926,3 +926,15 @@ def test_certified_reuse_shared_point_target(capi, ctx):
         g2_ = capi.linearize(tgt2, s1, capi.ICP, poses[-1], 2.0)
         assert s1.reuse_stats()["last_mode"] == capi.NN_FULL
     assert np.array_equal(r2, g2_)
+
+
+def test_quirk_q6_float64_target(capi, g9):
+    """PlaneICP.set_target with a float64 target (quirk Q6, plane_icp.py:20-22): the class casts to float32 for the
+    search AND the gather; the reference searches the float64 array.  Same H / pose within the bars on the fixture."""
+    import point_cloud_registration_amd as pcr
+    p = pcr.PlaneICP(max_dist=float(g9["max_dist"]), k=int(g9["k"]))
+    p.set_target(g9["target"], "tree", g9["plane_normals"])
+    for tag, T in (("T", g9["T"]), ("I", np.eye(4))):
+        H, g, e2 = p.calc_H_g_e2(T, g9["source"])
+        assert rel_H(H, g9[f"{tag}_plane_H"]) < TOL_REF
+    assert _pose_close(p.align(g9["source"], np.eye(4)), g9["align_final"])

@@ -165,8 +165,9 @@ def test_g6_normals(g6, k):
     _, idx = orc.knn_brute(pts, pts, k)
     n = orc.normals_from_knn(pts, idx, compat=True)
     dots = np.abs(np.sum(n * g6[f"normals_k{k}"], axis=1))
-    # float32 covariance + float32 LAPACK eigh in the reference: compare where well conditioned
-    assert np.mean(dots > 0.999) > 0.9
+    # (the thresholds of the full-scale g7 test; measured here: every normal within 1e-7 of the reference's)
+    assert np.mean(dots > 0.999) >= 0.999, np.mean(dots > 0.999)
+    assert np.mean(dots > 1 - 1e-5) > 0.99
 
 
 @pytest.mark.parametrize("k", [5, 15])
@@ -182,3 +183,52 @@ def test_g7_normals_full_scale(g7, k):
     dots = np.abs(np.sum(n.astype(np.float64) * g7[f"normals_k{k}"][pick], axis=1))
     assert np.mean(dots > 0.999) >= 0.999, np.mean(dots > 0.999)
     assert np.mean(dots > 1 - 1e-5) > 0.99
+
+
+# ----------------------------------------------------------------------------- g8: BASELINE size
+def _pose_err(T, ref):
+    dR = T[:3, :3] @ ref[:3, :3].T
+    ang = np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))
+    return float(np.max(np.abs(T[:3, 3] - ref[:3, 3]))), float(ang)
+
+
+@pytest.mark.parametrize("scan_name", ["harness100k", "pert100k"])
+def test_g8_oracle_matches_reference_at_b01_size(g8, scan_name):
+    """the 1e-5 / 1e-4 bars against the REFERENCE at the size the metric is quoted on (1.06 M-point
+    target, |p| up to 67 m, M = 1e5 correspondences, where the reference's float32 partial sums are largest): the
+    oracle's H, g, e2 at the identity and at every mid pose of the reference's own align() trajectory, then the
+    oracle's own align(): same iteration count, same final pose.  (PlaneICP with the supplied analytic normals: the
+    oracle's brute-force k-NN cannot estimate 1.06 M normals in a test; the reference's own-normal variant is
+    checked on the GPU.)"""
+    target, scan = g8["target"], g8[scan_name]
+    md = float(g8["max_dist"])
+    tp = orc.TargetPoints(target, normals=g8["given_normals"], cell=0.5)
+    tv = orc.TargetVoxels(target, float(g8["voxel_size"]))
+    assert tv.mean.shape[0] == int(g8["n_voxels"])
+    for cname, kind, tgt in (("icp", orc.ICP, tp), ("planeg", orc.PLANE, tp), ("vplane", orc.VPLANE, tv), ("ndt", orc.NDT, tv)):
+        tag = f"{scan_name}_{cname}"
+        Ts = g8[f"{tag}_T"]
+        for k in range(Ts.shape[0]):
+            H, g, e2 = orc.calc_H_g_e2(kind, tgt, Ts[k], scan, md)
+            assert rel_H(H, g8[f"{tag}_H"][k]) <= 1e-5, (tag, k, rel_H(H, g8[f"{tag}_H"][k]))
+            # g cancels towards convergence: relative to the gradient at the start of the run
+            assert np.max(np.abs(g - g8[f"{tag}_g"][k])) <= 1e-4 * np.max(np.abs(g8[f"{tag}_g"][0])), (tag, k)
+            assert abs(e2 - g8[f"{tag}_e2"][k]) <= 1e-4 * abs(g8[f"{tag}_e2"][k]), (tag, k)
+        trace = []
+        T = orc.align(kind, tgt, scan, max_iter=30, tol=1e-3, max_dist=md, trace=trace)
+        assert len(trace) == Ts.shape[0], (tag, len(trace), Ts.shape[0])
+        dt, dr = _pose_err(T, g8[f"{tag}_final"])
+        assert dt <= 1e-4 and dr <= 1e-4, (tag, dt, dr)
+
+
+def test_g9_quirk_q6_float64_target(g9):
+    """Quirk Q6: the reference's PlaneICP searches a tree built on the ORIGINAL float64 array (plane_icp.py:22) and
+    gathers from the float32 copy; here both are the float32 copy.  On a float64 target whose coordinates are not
+    float32-representable the neighbours are the same (the fixture records 0 differences of 2000) and H, g, e2
+    agree within the usual bars."""
+    assert np.array_equal(g9["nn_idx_f64_tree"], g9["nn_idx_f32_tree"])
+    tp = orc.TargetPoints(g9["target"].astype(np.float32), normals=g9["plane_normals"])
+    for tag, T in (("T", g9["T"]), ("I", np.eye(4))):
+        H, g, e2 = orc.calc_H_g_e2(orc.PLANE, tp, T, g9["source"], float(g9["max_dist"]))
+        assert rel_H(H, g9[f"{tag}_plane_H"]) < TOL_H
+        assert rel_H(g, g9[f"{tag}_plane_g"]) < 10 * TOL_H
