@@ -231,4 +231,5 @@ def test_g9_quirk_q6_float64_target(g9):
     for tag, T in (("T", g9["T"]), ("I", np.eye(4))):
         H, g, e2 = orc.calc_H_g_e2(orc.PLANE, tp, T, g9["source"], float(g9["max_dist"]))
         assert rel_H(H, g9[f"{tag}_plane_H"]) < TOL_H
-        assert rel_H(g, g9[f"{tag}_plane_g"]) < 10 * TOL_H
+        # (g cancels to ~0 at the true pose "T": measured against the gradient at the identity)
+        assert np.max(np.abs(g - g9[f"{tag}_plane_g"])) < 10 * TOL_H * np.max(np.abs(g9["I_plane_g"]))
