@@ -1606,8 +1606,7 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
 // queue a couple of iterations ahead of the GPU and watches two words in pinned memory: no host round
 // trip, no device-to-host copy and no host solve between iterations.  Launches that arrive after
 // convergence see pose->done and return at once.  With a communicator the 29 sums are all-reduced
-// between the fold and the step (k_gn_update); iterations are then enqueued in fixed batches so that
-// every rank issues the same sequence of collectives.
+// between the fold and the step (k_gn_update); every rank issues the same number of collectives (see below).
 pcr_status pcr_run_align(pcr_target *t, pcr_scan *s, int kind, const double T_init[16], int max_iter, double tol,
                          double max_dist, unsigned flags, double T_out[16], int *iterations, double *trace_or_null) {
     Pass ps;
@@ -1642,46 +1641,54 @@ pcr_status pcr_run_align(pcr_target *t, pcr_scan *s, int kind, const double T_in
 
     auto passes_done = [&] { return (int)(unsigned)(*state & 0xffffffffull); };
     auto loop_done = [&] { return (int)(unsigned)(*state >> 32); };
+    // One iteration = the pass, (multi-GPU) the in-stream all-reduce of its 29 sums, the one-wave update.  The host
+    // keeps the queue AHEAD iterations beyond the one the GPU reports and never waits on the stream.
+    // Multi-GPU: every rank must issue the SAME number of collectives, but each reads the (identical, all-reduced)
+    // state word at its own time.  A rank enqueues iteration e only while e < passes_done + AHEAD, so when it sees
+    // the loop end after `it` passes it has enqueued at most min(max_iter, it + AHEAD) iterations -- a number every
+    // rank can compute; each tops its queue up to exactly that (launches behind the end are no-ops, their
+    // all-reduces move stale sums): no host synchronisation between iterations, at most AHEAD dead all-reduces.
+    const int AHEAD = 2;
     int enq = 0;
-    if (!use_comm) {
-        const int AHEAD = 2;            // iterations kept in the queue beyond the one the GPU reports
-        long spin = 0;
-        for (;;) {
-            if (loop_done() != PCR_LOOP_RUNNING) break;
-            const int fin = passes_done();
-            if (enq < max_iter && enq < fin + AHEAD) {
-                retire_completed(ctx);
-                PCR_TRY(pass_enqueue(&ps));
-                hipLaunchKernelGGL(k_gn_update, dim3(1), dim3(64), 0, ctx->stream, f);
-                HIP_TRY(hipGetLastError());
-                ++enq; spin = 0;
-                continue;
-            }
-            __builtin_ia32_pause();
-            if (++spin > 4000000L) {    // a very long pass (or a fault): block, then look again
-                HIP_TRY(hipStreamSynchronize(ctx->stream));
-                if (loop_done() == PCR_LOOP_RUNNING && passes_done() == fin && !(enq < max_iter)) {
-                    pcr_set_error("device Gauss-Newton loop made no progress");
-                    return PCR_ERR_HIP;
-                }
-                spin = 0;
-            }
+    auto enqueue_iteration = [&]() -> pcr_status {
+        retire_completed(ctx);
+        PCR_TRY(pass_enqueue(&ps));
+        if (use_comm) {
+            ProfEvent ev;
+            pcr_prof_begin(ctx, PCR_K_ALLREDUCE, &ev);
+            pcr_status cs = pcr_comm_allreduce29(ctx, ctx->d_out);
+            pcr_prof_end(ctx, &ev);
+            if (cs != PCR_OK) return cs;
         }
-    } else {
-        const int BATCH = 4;
-        while (loop_done() == PCR_LOOP_RUNNING && enq < max_iter) {
-            for (int b = 0; b < BATCH && enq < max_iter; ++b, ++enq) {
-                PCR_TRY(pass_enqueue(&ps));
-                ProfEvent ev;
-                pcr_prof_begin(ctx, PCR_K_ALLREDUCE, &ev);
-                pcr_status cs = pcr_comm_allreduce29(ctx, ctx->d_out);
-                pcr_prof_end(ctx, &ev);
-                if (cs != PCR_OK) return cs;
-                hipLaunchKernelGGL(k_gn_update, dim3(1), dim3(64), 0, ctx->stream, f);
-                HIP_TRY(hipGetLastError());
-            }
-            HIP_TRY(hipStreamSynchronize(ctx->stream));    // every rank reads the same state here
+        hipLaunchKernelGGL(k_gn_update, dim3(1), dim3(64), 0, ctx->stream, f);
+        HIP_TRY(hipGetLastError());
+        ++enq;
+        return PCR_OK;
+    };
+    long spin = 0;
+    for (;;) {
+        if (loop_done() != PCR_LOOP_RUNNING) break;
+        const int fin = passes_done();
+        if (enq < max_iter && enq < fin + AHEAD) {
+            PCR_TRY(enqueue_iteration());
+            spin = 0;
+            continue;
         }
+        __builtin_ia32_pause();
+        if (++spin > 4000000L) {    // a very long pass (or a fault): block, then look again
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (loop_done() == PCR_LOOP_RUNNING && passes_done() == fin && !(enq < max_iter)) {
+                pcr_set_error("device Gauss-Newton loop made no progress");
+                return PCR_ERR_HIP;
+            }
+            spin = 0;
+        }
+    }
+    if (use_comm) {
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        const int it_end = passes_done();
+        const int target = it_end + AHEAD < max_iter ? it_end + AHEAD : max_iter;
+        while (enq < target) PCR_TRY(enqueue_iteration());
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     const int done = loop_done(), it = passes_done();

@@ -33,13 +33,24 @@ def _worker(rank, world, port, q):
     g2 = load_golden("g2_mini_street.npz")
     ctx = _capi.get_context(0)
     comm = pdist.Communicator(ctx, in_library=True)          # RCCL init fails (same GPU twice) -> agreed fallback
-    icp = pcr.PlaneICP(max_dist=float(g2["max_dist"]), k=int(g2["k"]), comm=comm)
-    icp.set_target(g2["target"], None, None)
-    icp.set_target(g2["target"], icp.kdtree, g2["plane_normals"])
+    md, vs = float(g2["max_dist"]), float(g2["voxel_size"])
     shard = pdist.shard_scan(g2["source"], rank, world)
-    T = icp.align(shard, np.eye(4))
-    H, g, e2 = icp.calc_H_g_e2(g2["T"], shard)
-    q.put((rank, comm.in_library, T, H, icp.last_iterations, icp.last_correspondences))
+    out = {}
+    for name in ("plane", "icp", "vplane", "ndt"):             # all four kinds through the sharded path
+        if name == "plane":
+            reg = pcr.PlaneICP(max_dist=md, k=int(g2["k"]), comm=comm)
+            reg.set_target(g2["target"], None, None)
+            reg.set_target(g2["target"], reg.kdtree, g2["plane_normals"])
+        elif name == "icp":
+            reg = pcr.ICP(max_dist=md, comm=comm); reg.set_target(g2["target"])
+        elif name == "vplane":
+            reg = pcr.VPlaneICP(voxel_size=vs, max_dist=md, comm=comm); reg.set_target(g2["target"])
+        else:
+            reg = pcr.NDT(voxel_size=vs, max_dist=md, comm=comm); reg.set_target(g2["target"])
+        T = reg.align(shard, np.eye(4))
+        H, g, e2 = reg.calc_H_g_e2(g2["T"], shard)
+        out[name] = (T, H, reg.last_iterations, reg.last_correspondences)
+    q.put((rank, comm.in_library, out))
     dist.barrier()
     comm.close()
     dist.destroy_process_group()
@@ -57,14 +68,16 @@ def test_two_ranks_one_gpu_sharded_plane_icp(g2):
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    (_, lib_a, Ta, Ha, ita, ca), (_, lib_b, Tb, Hb, itb, cb) = res
+    (_, lib_a, out_a), (_, lib_b, out_b) = res
     assert lib_a == lib_b                                     # both ranks took the same transport
     print("transport:", "RCCL inside libpcr_hip.so" if lib_a else "host all-reduce (gloo) fallback")
-    assert np.array_equal(Ta, Tb) and np.array_equal(Ha, Hb) and ita == itb and ca == cb
-    assert ita == g2["align_plane_T"].shape[0]
-    final = g2["align_plane_final"]
-    assert np.max(np.abs(Ta[:3, 3] - final[:3, 3])) < 1e-4
-    assert np.max(np.abs(Ha - g2["T_plane_H"])) < 1e-5 * np.max(np.abs(g2["T_plane_H"]))
+    for name in ("plane", "icp", "vplane", "ndt"):
+        (Ta, Ha, ita, ca), (Tb, Hb, itb, cb) = out_a[name], out_b[name]
+        assert np.array_equal(Ta, Tb) and np.array_equal(Ha, Hb) and ita == itb and ca == cb, name
+        assert ita == g2[f"align_{name}_T"].shape[0], name    # the sharded run = the reference's single-process run
+        final = g2[f"align_{name}_final"]
+        assert np.max(np.abs(Ta[:3, 3] - final[:3, 3])) < 1e-4, name
+        assert np.max(np.abs(Ha - g2[f"T_{name}_H"])) < 1e-5 * np.max(np.abs(g2[f"T_{name}_H"])), name
 
 
 @pytest.mark.gpu
