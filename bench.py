@@ -348,6 +348,8 @@ def main():
                                               "kernel_ms": round(kern["reduce"]["avg_ms"], 5)}
         if per_rank is not None:
             line["per_rank_kernel_ms"] = per_rank
+        if world == 1 and not use_comm and not os.environ.get("PCR_BENCH_NO_RCCL_PROBE"):
+            line["rccl_1rank"] = rccl_one_rank_probe(ctx, step, args.steps, sync_all)
         if world == 1:
             line["seam"] = seam_timings(kind_name, target, scan, tgt, sc, kind, traj, max_dist, voxel_size, n_target)
         if world == 1 and not args.no_cpu_baseline:
@@ -359,6 +361,50 @@ def main():
         torch.distributed.barrier()
         comm.close()
         torch.distributed.destroy_process_group()
+
+
+def rccl_one_rank_probe(ctx, step, steps, sync_all):
+    """What the multi-GPU path adds to a pass, measured with a ONE-rank communicator on this GPU: the in-stream
+    ncclAllReduce(29 doubles) + the hand-off kernel (k_publish) sit between the fold and the host exactly as they
+    do at N = 8; only the xGMI hops are missing.  A baseline to judge the first real SCALE run against; never part
+    of ``value``.  Failures are reported, not raised."""
+    try:
+        import socket
+        import torch
+        from point_cloud_registration_amd import distributed as pdist
+        if not torch.distributed.is_initialized():
+            s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(port))
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+            pdist.init_from_env("nccl")
+        comm = pdist.Communicator(ctx, in_library=True)
+        try:
+            if not comm.in_library:
+                return {"error": "RCCL communicator not available inside libpcr_hip.so"}
+            for k in range(5):
+                step(k)
+            ctx.profile_enable(True, period=1); ctx.profile_reset()
+            sync_all()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                step(k)
+            sync_all()
+            dt = time.perf_counter() - t0
+            prof = ctx.profile_read(); ctx.profile_enable(False)
+            sync_all()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                step(k)
+            sync_all()
+            dt_off = time.perf_counter() - t0
+            n, ms = prof["allreduce"]
+            return {"ms_per_step_events_off": round(dt_off / steps * 1e3, 4), "ms_per_step_profiled": round(dt / steps * 1e3, 4),
+                    "allreduce29_plus_publish_avg_ms": round(ms / max(n, 1), 5), "launches": n}
+        finally:
+            comm.close()
+            torch.distributed.destroy_process_group()
+    except Exception as e:                                   # noqa: BLE001 -- a probe must not take the bench line down
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
 def seam_timings(kind_name, target, scan, tgt, sc, kind, traj, max_dist, voxel_size, n_target):

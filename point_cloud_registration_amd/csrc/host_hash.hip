@@ -8,6 +8,7 @@
 // multiply-mix, four independent lanes per chunk), chunk digests folded in order -- the value does not depend on
 // the number of threads.  Not cryptographic; 64 bits: a collision needs ~2^32 distinct scans.
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -125,6 +126,8 @@ extern "C" pcr_status pcr_hash64(const void *data, uint64_t nbytes, uint64_t *ou
     if (!g_pool) {
         unsigned hw = std::thread::hardware_concurrency();
         int n = hw >= 32 ? 15 : (hw >= 8 ? 7 : (hw >= 2 ? (int)hw - 1 : 0));
+        const char *e = getenv("PCR_HASH_THREADS");           // (developer: worker threads beside the caller)
+        if (e && *e) { n = atoi(e); if (n < 0) n = 0; if (n > 63) n = 63; }
         g_pool = new Pool(n);                               // lives until the process exits
     }
     *out = g_pool->run((const uint8_t *)data, (size_t)nbytes);

@@ -137,7 +137,11 @@ class Registration:
         1e6 float32 points on the GPU box's host; no optional Python dependency)."""
         if src.size == 0:
             return 0
-        return _capi.hash64(src if src.flags.c_contiguous else np.ascontiguousarray(src))
+        if src.flags.c_contiguous:
+            return _capi.hash64(src)
+        if src.flags.f_contiguous:                # (a transposed result, e.g. (R @ P.T).T: hash its buffer as it lies)
+            return _capi.hash64(src.T) ^ 0x5bd1e995
+        return _capi.hash64(np.ascontiguousarray(src))
 
     def _scan_for(self, source, fresh=False):
         """Upload (and Morton-sort) the scan; ``calc_H_g_e2`` called repeatedly with the same array

@@ -117,7 +117,7 @@ def harness_scan(target, num_points=100_000, so3=(0.0, 0.0, 0.0), t=(0.0, 0.0, 0
     idx = rng.choice(scan.shape[0], num_points, replace=False)
     scan = scan[idx]
     scan += rng.normal(0.0, noise, scan.shape)
-    return scan.astype(np.float32)
+    return np.ascontiguousarray(scan, dtype=np.float32)
 
 
 def perturbed_scan(target, num_points=None, noise=0.005, seed=2,
@@ -133,4 +133,4 @@ def perturbed_scan(target, num_points=None, noise=0.005, seed=2,
         pts = target[idx]
     scan = (Rinv @ pts.astype(np.float64).T).T + tinv
     scan += rng.normal(0.0, noise, scan.shape)
-    return scan.astype(np.float32), T
+    return np.ascontiguousarray(scan, dtype=np.float32), T      # (C order: (R @ P.T).T is a transposed view)
