@@ -34,6 +34,13 @@ import os
 import sys
 import time
 
+# Host hygiene, before NumPy loads its BLAS: on a 256-CPU box inside a container with a 16-CPU quota the BLAS thread
+# pool (one spinning thread per visible CPU after the first matmul) exhausts the cgroup's CPU bandwidth and the
+# kernel parks EVERY thread of the process for the rest of the 100 ms period -- the "12-42 ms launch stalls" of
+# round 2 (root-caused in round 3: profiles/r03_stall_root_cause.txt).  The oracle's OpenMP pool (cpu_baseline) is
+# not affected by this variable.
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "8")
+
 import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))

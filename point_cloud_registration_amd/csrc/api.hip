@@ -113,6 +113,10 @@ extern "C" pcr_status pcr_context_create(int device, pcr_context **out) {
     if (ff && *ff) ctx->fuse_finalize = atoi(ff) != 0;
     const char *tl = getenv("PCR_TILE_LOCAL");
     if (tl && *tl) ctx->tile_local = atoi(tl) != 0;
+    const char *sd = getenv("PCR_STALL_DEBUG");
+    if (sd && *sd) ctx->stall_debug = atoi(sd) != 0;
+    const char *rp = getenv("PCR_RETIRE_PERIOD");
+    if (rp && *rp) ctx->retire_period = atoi(rp);
     const char *ru = getenv("PCR_REUSE");
     if (ru && *ru) ctx->reuse = atoi(ru);
     const char *rt = getenv("PCR_REUSE_TAU");

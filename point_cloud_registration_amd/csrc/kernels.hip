@@ -26,6 +26,7 @@
 // entries reach 1e11 at 1e8 points, float32 would lose the 1e-5 parity bar); the 32 sums are folded
 // across the wave with a halving butterfly (32 shuffles instead of 32 x 6), then across waves through LDS.
 #include <string.h>
+#include <time.h>
 
 #include "gn_math.h"
 #include "nn_device.h"
@@ -1528,15 +1529,21 @@ static pcr_status wait_host_word(pcr_context *ctx, Pred ready, const char *what)
     return PCR_OK;
 }
 
-// The zero-copy hand-off never calls into the HIP runtime between launches, so the runtime never gets
-// to retire finished commands.  Observed (tools/stall_probe.py): about once per 1500 unprofiled passes,
-// mostly early in a process, ONE call blocks for 12-42 ms -- not in the spin above (it returns within
-// microseconds) but in a launch; never seen with HIP events around the passes (they retire commands as
-// they go).  Querying the idle stream every 8th pass made the stalls ~10x rarer (1 in 18 000 passes) but a
-// query turned out to cost ~50 us (+4 % on a 1.06 M-point pass); it is done every 64th pass (< 1 us per
-// pass).  bench.py's median over blocks is immune either way; ms_per_step_max shows a stall when one hits.
+// Rare 6-60 ms stalls of ONE call early in a process ("12-42 ms, about once per 1500 passes") were
+// root-caused in round 3 (tools/stall_study.py, PCR_STALL_DEBUG=1; profiles/r03_stall_root_cause.txt): the calling
+// thread is DESCHEDULED -- on a CPU for 0.03-0.08 ms of a 41 ms stall -- while the container's cgroup reports one
+// more throttled period (cpu.max = 16 CPUs per 100 ms on the GPU box): the thread pools of the host libraries
+// (256 visible CPUs) burn the CPU quota during start-up and the kernel parks every thread of the cgroup until the
+// next period.  Durations are 6.6 ms + k x 10 ms (scheduler ticks); the stall lands in the enqueue or in the spin,
+// wherever the thread happens to be.  Neither the GPU nor the HIP runtime is involved: with the host thread pools
+// capped (OMP_NUM_THREADS / OPENBLAS_NUM_THREADS) 25 of 25 fresh processes and 1e6 consecutive passes stay below
+// 1 ms.  The hipStreamQuery cadence of round 2 rested on a wrong theory (20 of 25 processes stalled with it, 23 of
+// 25 without); it is kept only as an opt-in knob (PCR_RETIRE_PERIOD, default off).
 static void retire_completed(pcr_context *ctx) {
-    if ((++ctx->passes_since_query & 63u) == 0) (void)hipStreamQuery(ctx->stream);
+    if (ctx->retire_period > 0 && ++ctx->passes_since_query >= (uint32_t)ctx->retire_period) {
+        ctx->passes_since_query = 0;
+        (void)hipStreamQuery(ctx->stream);
+    }
 }
 
 pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double T[16], double max_dist,
@@ -1557,7 +1564,11 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
     ps.f.host_flag = direct ? (volatile uint32_t *)(ctx->h_out_dev + 32) : nullptr;
     const uint32_t seq = ++ctx->seq;
     ps.f.seq = seq;
+    const bool stall_dbg = ctx->stall_debug;
+    struct timespec ts0, ts1, ts2, tc0, tc2;
+    if (stall_dbg) { clock_gettime(CLOCK_MONOTONIC, &ts0); clock_gettime(CLOCK_THREAD_CPUTIME_ID, &tc0); }
     PCR_TRY(pass_enqueue(&ps));
+    if (stall_dbg) clock_gettime(CLOCK_MONOTONIC, &ts1);
     // what this pass leaves behind for the next one over the same scan
     memcpy(s->prev_T, T, sizeof s->prev_T);
     s->pose_valid = !ps.one_kernel;
@@ -1582,6 +1593,16 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
     }
     if (flagged) {
         PCR_TRY(wait_host_word(ctx, [&] { return *flag == seq; }, "finalize kernel"));
+        if (stall_dbg) {                     // developer (PCR_STALL_DEBUG): where did a slow call spend its time?
+            clock_gettime(CLOCK_MONOTONIC, &ts2); clock_gettime(CLOCK_THREAD_CPUTIME_ID, &tc2);
+            const double cpu = (tc2.tv_sec - tc0.tv_sec) * 1e3 + (tc2.tv_nsec - tc0.tv_nsec) * 1e-6;
+            const double enq = (ts1.tv_sec - ts0.tv_sec) * 1e3 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-6;
+            const double wait = (ts2.tv_sec - ts1.tv_sec) * 1e3 + (ts2.tv_nsec - ts1.tv_nsec) * 1e-6;
+            if (enq + wait > 1.0) {
+                fprintf(stderr, "[pcr stall] seq %u: enqueue %.3f ms, wait for the result %.3f ms; this thread was ON a CPU for %.3f ms of it\n",
+                        seq, enq, wait, cpu);
+            }
+        }
         for (int i = 0; i < 29; ++i) out[i] = ctx->h_out[i];
         if (mode == PCR_NN_LIST && direct) {
             s->last_marked = (int64_t)ctx->h_out[29];

@@ -174,6 +174,8 @@ struct pcr_context {
     double *h_out_dev = nullptr;    // device-side address of h_out
     uint32_t seq = 0;
     uint32_t passes_since_query = 0;   // see retire_completed (kernels.hip)
+    bool stall_debug = false;          // PCR_STALL_DEBUG: report where a pass slower than 1 ms spent its time
+    int retire_period = 0;             // hipStreamQuery every n-th pass (PCR_RETIRE_PERIOD; 0 = never, the default)
     // device-resident Gauss-Newton loop: pose in HBM, per-iteration trace rows (16 + 29 doubles),
     // progress words in pinned host memory ([0] iter, [1] done, then 16 doubles of pose)
     PoseDev *d_pose = nullptr;
