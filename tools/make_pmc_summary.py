@@ -9,7 +9,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import bench
 
-HOT = ("k_nn_scan", "k_nn_coop", "k_reduce_finalize", "k_reduce", "k_linearize", "k_finalize", "k_gn_update")
+HOT = ("k_nn_scan", "k_certify", "k_nn_coop", "k_reduce_finalize", "k_reduce", "k_linearize", "k_finalize", "k_gn_update")
 
 
 def parse(path, counter):
@@ -27,7 +27,7 @@ def parse(path, counter):
 def main():
     commit = subprocess.run(["git", "-C", REPO, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
     summary = {"_comment": __doc__.replace("\n", " "), "kernel_source_hash": bench.kernel_source_hash(), "commit": commit}
-    for cfg, tag in (("plane_b01", "r02_plane_b01"), ("plane_100m", "r02_plane_100m"), ("icp_b01_harness", "r02_icp_b01_harness")):
+    for cfg, tag in (("plane_b01", "r03_plane_b01"), ("plane_100m", "r03_plane_100m"), ("icp_b01_harness", "r03_icp_b01_harness")):
         f = parse(os.path.join(REPO, "profiles", tag + "_pmc_fetch.txt"), "FETCH_SIZE")
         w = parse(os.path.join(REPO, "profiles", tag + "_pmc_write.txt"), "WRITE_SIZE")
         if not f:
