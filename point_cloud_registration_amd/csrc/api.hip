@@ -111,6 +111,8 @@ extern "C" pcr_status pcr_context_create(int device, pcr_context **out) {
     if (nm && *nm) ctx->nn_mode = atoi(nm);
     const char *ff = getenv("PCR_FUSE_FINALIZE");
     if (ff && *ff) ctx->fuse_finalize = atoi(ff) != 0;
+    const char *lf = getenv("PCR_LOCAL_FRAC");
+    if (lf && *lf) ctx->local_frac = atof(lf);
     const char *tl = getenv("PCR_TILE_LOCAL");
     if (tl && *tl) ctx->tile_local = atoi(tl) != 0;
     const char *sd = getenv("PCR_STALL_DEBUG");

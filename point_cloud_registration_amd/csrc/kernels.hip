@@ -168,28 +168,36 @@ __global__ void __launch_bounds__(256, 5) k_nn_scan(const LinArgs a) {
         __shared__ uint32_t lst_n;
         nn_chunk_loop(a, [&](int64_t first, int64_t end) { nn_chunk_list<VOXEL, HALO>(a, P, Q, lst, &lst_n, first, end); });
     } else {
-        nn_tile_loop<LOCAL, 64>(a, [&](int64_t first, int64_t end) {
+        auto body = [&](int64_t first, int64_t end) {
             const int64_t i = first + (threadIdx.x & 63);
             if (i < end) nn_point<VOXEL, HALO, MODE == PCR_NN_TRACK>(a, P, Q, i);
-        });
+        };
+        if (LOCAL == 2) {       // device-resident loop: k_gn_update decided from the size of its step (PoseDev::tile_local)
+            if (__builtin_amdgcn_readfirstlane(a.pose->tile_local)) nn_tile_loop<1, 64>(a, body);
+            else nn_tile_loop<0, 64>(a, body);
+        } else {
+            nn_tile_loop<LOCAL, 64>(a, body);
+        }
     }
 }
 
 // host-side choice of the instantiation
+// (local: 0 global counters, 1 block-local, 2 decided on the device -- plain searches of the device-resident loop only)
 template <int VOXEL, int MODE>
-static void launch_nn_scan_mode(bool halo, bool local, dim3 grid, hipStream_t st, const LinArgs &a) {
+static void launch_nn_scan_mode(bool halo, int local, dim3 grid, hipStream_t st, const LinArgs &a) {
     const dim3 block(256);
 #define PCR_NN_CASE(H, L) hipLaunchKernelGGL((k_nn_scan<VOXEL, (VOXEL ? 0 : H), L, MODE>), grid, block, 0, st, a)
+    if (MODE == PCR_NN_FULL && local == 2) { if (halo) PCR_NN_CASE(1, 2); else PCR_NN_CASE(0, 2); return; }
     if (halo) { if (local) PCR_NN_CASE(1, 1); else PCR_NN_CASE(1, 0); }
     else { if (local) PCR_NN_CASE(0, 1); else PCR_NN_CASE(0, 0); }
 #undef PCR_NN_CASE
 }
 template <int VOXEL>
-static void launch_nn_scan(int mode, bool halo, bool local, dim3 grid, hipStream_t st, const LinArgs &a) {
+static void launch_nn_scan(int mode, bool halo, int local, dim3 grid, hipStream_t st, const LinArgs &a) {
     switch (mode) {
     case PCR_NN_FULL: launch_nn_scan_mode<VOXEL, PCR_NN_FULL>(halo, local, grid, st, a); break;
-    case PCR_NN_TRACK: launch_nn_scan_mode<VOXEL, PCR_NN_TRACK>(halo, local, grid, st, a); break;
-    default: launch_nn_scan_mode<VOXEL, PCR_NN_LIST>(halo, false, grid, st, a); break;
+    case PCR_NN_TRACK: launch_nn_scan_mode<VOXEL, PCR_NN_TRACK>(halo, local != 0, grid, st, a); break;
+    default: launch_nn_scan_mode<VOXEL, PCR_NN_LIST>(halo, 0, grid, st, a); break;
     }
 }
 
@@ -206,7 +214,11 @@ __device__ __forceinline__ void gn_update(const FinArgs &f, double (*A)[7]) {
         for (int i = 0; i < 16; ++i) row[i] = T[i];
         for (int i = 0; i < 29; ++i) row[16 + i] = f.out[i];
     }
+    double T_old[16];
+    for (int i = 0; i < 16; ++i) T_old[i] = T[i];
     const int r = gn_step(A, f.out, f.tol, T);
+    // hand-out policy of the next search (see pass_enqueue): block-local once the scan moves by less than local_len
+    p->tile_local = (r == 0 && f.local_len > 0.0 && gn_typical_motion(T_old, T, f.bb_c, f.bb_e) < f.local_len) ? 1 : 0;
     int done = r == 2 ? PCR_LOOP_SINGULAR : (r == 1 ? PCR_LOOP_CONVERGED : PCR_LOOP_RUNNING);
     if (r == 0) {
         for (int i = 0; i < 16; ++i) p->T[i] = T[i];
@@ -250,6 +262,7 @@ __global__ void __launch_bounds__(64) k_pose_init(PoseDev *p, const PoseInit ini
     }
     p->iter = 0;
     p->done = max_iter > 0 ? PCR_LOOP_RUNNING : PCR_LOOP_MAXITER;
+    p->tile_local = 0;
 }
 
 // k_reduce with the fold inside (the shipped reduce kernel)
@@ -356,6 +369,7 @@ struct Pass {
     FinArgs f;
     bool one_kernel;     // fused search + reduce kernel (variant 0, or variant 2 on a small scan)
     bool fused_fin;      // the fold of the block partials inside the producing kernel instead of k_finalize
+    double motion;       // typical displacement of the scan since the previous pass over it (host-driven passes; -1 unknown)
     int nn_mode;         // PCR_NN_FULL / TRACK / LIST
     bool reuse_ready;    // the scan has the buffers of the certified-reuse path
 };
@@ -431,8 +445,11 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
     if (a.nblocks < 8) a.nblocks = 8;
     ps->fused_fin = ctx->fuse_finalize;
     ps->nn_mode = PCR_NN_FULL;
+    ps->motion = -1.0;
     FinArgs &f = ps->f;
     memset(&f, 0, sizeof f);
+    for (int i = 0; i < 3; ++i) { f.bb_c[i] = s->bb_c[i]; f.bb_e[i] = s->bb_e[i]; }
+    f.local_len = ctx->local_frac * (t->is_voxel ? t->gd.h : (double)t->gf.h);
     f.ucnt = s->ucnt; f.n_ucnt = a.nblocks;
     f.partials = ctx->d_partials; f.tile_ctr = ctx->d_tile_ctr + 9 * 16; f.tickets = ctx->d_tile_ctr; f.nblocks = a.nblocks; f.kind = kind; f.out = ctx->d_out;
     return PCR_OK;
@@ -471,12 +488,12 @@ static int host_choose_mode(const Pass *ps, const double T[16], double *motion_o
     const pcr_scan *s = ps->s;
     const pcr_target *t = ps->t;
     *motion_out = -1.0;
-    if (!ps->reuse_ready) return PCR_NN_FULL;
     const int have_prev = s->pose_valid && s->nn_serial == t->serial && s->nn_serial != 0;
     if (!have_prev) return PCR_NN_FULL;
     const double h = t->is_voxel ? t->gd.h : (double)t->gf.h;
     const double m = gn_typical_motion(s->prev_T, T, s->bb_c, s->bb_e);
     *motion_out = m;
+    if (!ps->reuse_ready) return PCR_NN_FULL;
     return gn_choose_nn_mode(ctx->reuse, have_prev, s->track_valid ? 1 : 0, m, s->last_motion, ctx->reuse_tau * h);
 }
 
@@ -533,13 +550,22 @@ static pcr_status pass_enqueue(Pass *ps) {
             if (nb < 8) nb = 8;
             const dim3 nn_grid((unsigned)nb);
             // hand-out policy: at most ~1.5 tiles per launched wave -> block-local (nn_tile_loop)
-            ps->a.sched_local = ctx->tile_local >= 0 ? ctx->tile_local : (tiles * 2 <= nb * 4 * 3 ? 1 : 0);
+            // ... or the scan moved little since the previous pass: the far poses are where the cost of a tile varies 10x
+            // and the global counters pay (1.06 M points, per pose: 235 / 185 / 108 / 55 / 52 us with the counters,
+            // 221 / 203 / 111 / 51 / 40 block-local); the device-resident loop decides in k_gn_update (2)
+            int local = tiles * 2 <= nb * 4 * 3 ? 1 : 0;
+            if (!local && mode != PCR_NN_LIST) {
+                if (a.pose != nullptr) local = mode == PCR_NN_FULL ? 2 : 0;
+                else if (ps->motion >= 0.0 && ps->motion < ps->f.local_len) local = 1;
+            }
+            if (ctx->tile_local >= 0) local = ctx->tile_local;
+            ps->a.sched_local = local;
             if (!vox && ctx->nn_mode == 2) {
                 pcr_dev_launch_coop(nn_grid, ctx->stream, a);
             } else if (!vox) {
-                launch_nn_scan<0>(mode, ps->t->cs_h != nullptr, ps->a.sched_local != 0, nn_grid, ctx->stream, a);
+                launch_nn_scan<0>(mode, ps->t->cs_h != nullptr, ps->a.sched_local, nn_grid, ctx->stream, a);
             } else {
-                launch_nn_scan<1>(mode, false, ps->a.sched_local != 0, nn_grid, ctx->stream, a);
+                launch_nn_scan<1>(mode, false, ps->a.sched_local, nn_grid, ctx->stream, a);
             }
             ps->s->nn_serial = ps->t->serial;      // nn_j now holds matches against this target
         }
@@ -602,6 +628,7 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
     pass_set_host_pose(&ps, T);
     double motion = -1.0;
     const int mode = ps.one_kernel ? PCR_NN_FULL : host_choose_mode(&ps, T, &motion);
+    ps.motion = motion;
     pass_set_mode(&ps, mode);
     const bool use_comm = ctx->comm != nullptr && !(flags & PCR_FLAG_LOCAL_ONLY);
     // single GPU: the finalize step writes the result and a sequence number straight into pinned host

@@ -531,6 +531,9 @@ struct FinArgs {
     int nn_mode;
     const uint32_t *ucnt;
     int n_ucnt;
+    // bounding box of the scan and the displacement below which the next search deals its tiles block-locally
+    float bb_c[3], bb_e[3];
+    double local_len;
     // device-resident Gauss-Newton loop (pcr_align; registration.py:89-111 behind the boundary)
     PoseDev *pose;             // NULL: plain pass
     int max_iter;

@@ -81,6 +81,7 @@ struct PoseDev {
     float r32[9], t32[3];  // float32 copy used to transform the scan (math_tools.py:111-113)
     int iter;              // passes completed
     int done;              // 0 running, 1 converged, 2 singular, 3 max_iter reached
+    int tile_local;        // hand-out policy of the next search, decided by k_gn_update from the size of its step
 };
 #define PCR_LOOP_RUNNING 0
 #define PCR_LOOP_CONVERGED 1
@@ -184,6 +185,7 @@ struct pcr_context {
     int variant = 0;
     int nn_mode = 0;             // 0 per-lane search; 2 wave-cooperative (developer builds)
     // certified reuse of the previous pass' matches (see kernels.hip: choose_nn_mode)
+    double local_frac = 0.35;    // block-local tile hand-out when the scan moved less than this x cell size (PCR_LOCAL_FRAC)
     int tile_local = -1;         // PCR_TILE_LOCAL (developer): force the hand-out policy of k_nn_scan; -1 = automatic
     int reuse = 1;               // 0 off, 1 automatic, 2 forced (track + list whenever the state allows: tests)
     double reuse_tau = 0.08;     // try it when the scan's typical motion since the last pass is below tau x cell size
