@@ -10,7 +10,7 @@ out=$root/build/exp/$name
 mkdir -p "$out"
 flags="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -I$root/include -I$src $defs"
 pids=()
-for f in api kernels index_build comm voxel_build knn_normals host_hash; do
+for f in api kernels kernels_dev index_build comm voxel_build knn_normals host_hash; do
     # only kernels.hip sees the experiment macros; the other objects are reused from the main build when present
     if [ "$f" != "kernels" ] && [ -f "$src/$f.o" ] && [ -z "$ALL" ]; then cp "$src/$f.o" "$out/$f.o"; continue; fi
     /opt/rocm/bin/hipcc $flags -c "$src/$f.hip" -o "$out/$f.o" &
