@@ -318,7 +318,7 @@ static pcr_status upload(pcr_context *ctx, const T *host, size_t count, DevBuf<T
 
 static void target_free(pcr_target *t) {
     if (!t) return;
-    void *ptrs[] = {t->cell_start, t->cell_seed, t->cs_h, t->pts_h, t->j_h, t->pts, t->pn, t->means, t->vnorm, t->vicov,
+    void *ptrs[] = {t->cell_start, t->cell_seed, t->rowocc, t->cs_h, t->pts_h, t->j_h, t->pts, t->pn, t->means, t->vnorm, t->vicov,
                     t->st_mean, t->st_cov, t->st_norm, t->st_icov, t->st_counts, t->st_keys};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete t;

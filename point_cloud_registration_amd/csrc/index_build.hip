@@ -299,7 +299,7 @@ static bool make_geom(const float lo[3], const float hi[3], double h, Geom<Real>
     g->slack = (Real)(16.0 * eps * (mag + h) + 1e-30);
     g->cs_mask = 0xffffffffu;
     g->seed = nullptr;
-    g->halo = (Real)0; g->cs_h = nullptr; g->pts_h = nullptr; g->j_h = nullptr;
+    g->halo = (Real)0; g->cs_h = nullptr; g->pts_h = nullptr; g->j_h = nullptr; g->rowocc = nullptr; g->nyw = 0; g->nxb = 0;
     return true;
 }
 
@@ -450,7 +450,7 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
         occupied = (int64_t)nz2;
     }
     // ---- halo lists (point targets with a gap field: both share the 28-bit offsets)
-    g.halo = (Real)0; g.cs_h = nullptr; g.pts_h = nullptr; g.j_h = nullptr;
+    g.halo = (Real)0; g.cs_h = nullptr; g.pts_h = nullptr; g.j_h = nullptr; g.rowocc = nullptr; g.nyw = 0; g.nxb = 0;
     DevBuf<uint32_t> d_cs_h, d_j_h;
     DevBuf<PtF> d_pts_h;
     int64_t n_h = 0;
@@ -506,6 +506,39 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
     return PCR_OK;
 }
 
+// row-occupancy bitmap (Geom::rowocc): one thread per word = 64 rows x one 16-cell x-block
+__global__ void __launch_bounds__(256) k_row_occ(const uint32_t *__restrict__ cs, uint32_t mask, int nx, int ny, int nz, int nyw, int nxb,
+                                                 unsigned long long *out) {
+    const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= (int64_t)nz * nyw * nxb) return;
+    const int xb = (int)(w % nxb), wy = (int)((w / nxb) % nyw), z = (int)(w / ((int64_t)nxb * nyw));
+    const int x0 = xb * 16, x1 = min(x0 + 16, nx);
+    unsigned long long bits = 0;
+    for (int b = 0; b < 64; ++b) {
+        const int y = wy * 64 + b;
+        if (y >= ny) break;
+        const size_t row = ((size_t)z * ny + y) * (size_t)nx;
+        if ((cs[row + x1] & mask) != (cs[row + x0] & mask)) bits |= 1ull << b;
+    }
+    out[w] = bits;
+}
+
+template <typename Real>
+static pcr_status make_row_occ(pcr_context *ctx, const uint32_t *cs, Geom<Real> *g, unsigned long long **out) {
+    g->rowocc = nullptr; g->nyw = (g->ny + 63) / 64; g->nxb = (g->nx + 15) / 16;
+    const int64_t words = (int64_t)g->nz * g->nyw * g->nxb;
+    if (words <= 0) return PCR_OK;
+    DevBuf<unsigned long long> buf;
+    HIP_TRY(buf.alloc_exact((size_t)words));
+    hipLaunchKernelGGL(k_row_occ, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, cs, g->cs_mask, g->nx, g->ny, g->nz,
+                       g->nyw, g->nxb, buf.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *out = buf.release();
+    g->rowocc = *out;
+    return PCR_OK;
+}
+
 pcr_status pcr_count_nonfinite(pcr_context *ctx, const void *d_xyz, int is_f64, int64_t n, int64_t *count) {
     float lo[3], hi[3];
     if (is_f64) return device_bbox<double>(ctx, (const double *)d_xyz, n, lo, hi, count);
@@ -524,14 +557,18 @@ pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n,
     double halo = n <= ((int64_t)1 << 24) ? 0.1 : 0.0;
     const char *he = getenv("PCR_HALO");
     if (he && *he) halo = atof(he);
-    return build_grid<float, float, PtF>(ctx, d_xyz, n, h, auto_h, &t->gf, &t->cell_start, &t->cell_seed, &t->pts, &t->occupied,
-                                         halo, &t->cs_h, &t->pts_h, &t->j_h, &t->n_h);
+    PCR_TRY((build_grid<float, float, PtF>(ctx, d_xyz, n, h, auto_h, &t->gf, &t->cell_start, &t->cell_seed, &t->pts, &t->occupied,
+                                           halo, &t->cs_h, &t->pts_h, &t->j_h, &t->n_h)));
+    return PCR_OK;       // (no row-occupancy bitmap for point targets: measured slower, nn_device.h)
 }
 
 pcr_status pcr_build_centroid_grid(pcr_context *ctx, const double *d_mean, int64_t n, double cell, pcr_target *t) {
     uint32_t *cs_h = nullptr, *j_h = nullptr; PtF *pts_h = nullptr; int64_t n_h = 0;
-    return build_grid<double, double, PtD>(ctx, d_mean, n, cell, false, &t->gd, &t->cell_start, &t->cell_seed, &t->means, &t->occupied,
-                                           0.0, &cs_h, &pts_h, &j_h, &n_h);
+    PCR_TRY((build_grid<double, double, PtD>(ctx, d_mean, n, cell, false, &t->gd, &t->cell_start, &t->cell_seed, &t->means, &t->occupied,
+                                             0.0, &cs_h, &pts_h, &j_h, &n_h)));
+    const char *oe = getenv("PCR_ROW_OCC");
+    if (n > 0 && !(oe && atoi(oe) == 0)) PCR_TRY(make_row_occ<double>(ctx, t->cell_start, &t->gd, &t->rowocc));
+    return PCR_OK;
 }
 
 // ---- row permutations into cell-sorted order -------------------------------------------------

@@ -155,10 +155,15 @@ __device__ __forceinline__ void nn_chunk_loop(const LinArgs &a, Body &&body) {
 }
 
 // MODE: PCR_NN_FULL / PCR_NN_TRACK / PCR_NN_LIST
-// (5 waves per SIMD: the float64 centroid search sits at 101 VGPRs without the bound, which would cost it a
-// fifth of its occupancy and 10 % of its speed; the float32 search needs < 80 either way)
+// (the float32 search needs < 80 VGPRs: 6 waves per SIMD.  The float64 centroid search with the row-occupancy
+// bitmap wants ~110: bounded to 5 waves it spills 92 bytes per lane; at 4 waves it is the fastest form measured --
+// nn time over the trajectory, base / bitmap from ring 2 at 5 waves / the same at 4 waves / bitmap from ring 1 at 4 waves:
+// vplane_10m 7105 / 6538 / 6104 / 5978 us, ndt_10m 3777 / 4299 / 3982 / 3903 us)
+#ifndef PCR_VOX_WAVES
+#define PCR_VOX_WAVES 4
+#endif
 template <int VOXEL, int HALO, int LOCAL, int MODE>
-__global__ void __launch_bounds__(256, 5) k_nn_scan(const LinArgs a) {
+__global__ void __launch_bounds__(256, VOXEL ? PCR_VOX_WAVES : 5) k_nn_scan(const LinArgs a) {
     PoseK P;
     PoseQ Q;
     if (!load_pose<false>(a, P)) return;

@@ -56,6 +56,10 @@ struct Geom {
     const uint32_t *cs_h;
     const void *pts_h;
     const uint32_t *j_h;
+    // row-occupancy bitmap (nullptr = none): word ((z * nyw + (y >> 6)) * nxb + (x >> 4)), bit y & 63 = row (y, z) has a
+    // point in cells [16 (x >> 4), 16 (x >> 4) + 16): lets the wide rings of a far query skip empty rows 64 at a time
+    const unsigned long long *rowocc;
+    int nyw, nxb;
 };
 #define PCR_GAP_SHIFT 28
 #define PCR_GAP_MAX 15
@@ -218,6 +222,7 @@ struct pcr_target {
     int64_t occupied = 0;    // occupied cells of the NN grid
     uint32_t *cell_start = nullptr;
     uint32_t *cell_seed = nullptr;
+    unsigned long long *rowocc = nullptr;   // row-occupancy bitmap of the grid (Geom::rowocc)
     uint32_t *cs_h = nullptr;        // extended (halo) lists of point targets
     PtF *pts_h = nullptr;
     uint32_t *j_h = nullptr;

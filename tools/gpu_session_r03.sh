@@ -2,6 +2,7 @@
 # One GPU session of round 3: every bench config, per-pose / reuse probes, build timings, rocprofv3 passes.
 cd "$(dirname "$0")/.."
 o=gpurun_out; mkdir -p $o; export TMPDIR=/tmp
+timeout 2400 python -m pytest tests -m gpu -x -q > $o/r03_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $o/r03_pytest_gpu.log; tail -3 $o/r03_pytest_gpu.log
 for c in plane_b01 icp_b01 icp_b01_harness plane_b01_100k vplane_10m ndt_10m plane_100m plane_b01_resampled plane_b01_crop plane_100m_resampled; do
     timeout 900 python bench.py --config $c > $o/r03_bench_$c.json 2> $o/r03_bench_$c.err
     python - "$o/r03_bench_$c.json" <<'PY'
