@@ -192,7 +192,7 @@ struct pcr_context {
     double local_frac = 0.35;    // block-local tile hand-out when the scan moved less than this x cell size (PCR_LOCAL_FRAC)
     int tile_local = -1;         // PCR_TILE_LOCAL (developer): force the hand-out policy of k_nn_scan; -1 = automatic
     int reuse = 1;               // 0 off, 1 automatic, 2 forced (track + list whenever the state allows: tests)
-    double reuse_tau = 0.08;     // try it when the scan's typical motion since the last pass is below tau x cell size
+    double reuse_tau = 0.0125;   // try it when the scan's typical motion since the last pass is below tau x cell size (a quarter of mu)
     double reuse_mu = 0.05;      // margin of the tracking search, x cell size
     uint64_t next_serial = 1;    // targets get unique serial numbers (validity of a scan's previous matches)
     bool fuse_finalize = true;   // k_reduce_finalize (PCR_FUSE_FINALIZE=0: k_reduce + k_finalize)
