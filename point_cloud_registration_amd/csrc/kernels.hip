@@ -155,6 +155,9 @@ __device__ __forceinline__ void nn_chunk_loop(const LinArgs &a, Body &&body) {
 }
 
 // MODE: PCR_NN_FULL / PCR_NN_TRACK / PCR_NN_LIST
+// VOXEL: 0 point target (float32 search), 1 centroid search with the plain row loop, 2 centroid search that takes the rows
+// of a ring from the row-occupancy bitmap -- chosen per launch when the gate spans >= 5 rings of the centroid grid
+// (vplane_10m: 0.5 m voxels, 2 m gate; ndt_10m with 1 m voxels keeps the row loop, which is faster there).
 // (the float32 search needs < 80 VGPRs: 6 waves per SIMD.  The float64 centroid search with the row-occupancy
 // bitmap wants ~110: bounded to 5 waves it spills 92 bytes per lane; at 4 waves it is the fastest form measured --
 // nn time over the trajectory, base / bitmap from ring 2 at 5 waves / the same at 4 waves / bitmap from ring 1 at 4 waves:
@@ -163,7 +166,7 @@ __device__ __forceinline__ void nn_chunk_loop(const LinArgs &a, Body &&body) {
 #define PCR_VOX_WAVES 4
 #endif
 template <int VOXEL, int HALO, int LOCAL, int MODE>
-__global__ void __launch_bounds__(256, VOXEL ? PCR_VOX_WAVES : 5) k_nn_scan(const LinArgs a) {
+__global__ void __launch_bounds__(256, VOXEL == 2 ? PCR_VOX_WAVES : 5) k_nn_scan(const LinArgs a) {
     PoseK P;
     PoseQ Q;
     if (!load_pose<false>(a, P)) return;
@@ -571,6 +574,8 @@ static pcr_status pass_enqueue(Pass *ps) {
                 pcr_dev_launch_coop(nn_grid, ctx->stream, a);
             } else if (!vox) {
                 launch_nn_scan<0>(mode, ps->t->cs_h != nullptr, ps->a.sched_local, nn_grid, ctx->stream, a);
+            } else if (ps->t->gd.rowocc != nullptr && a.md_d / ps->t->gd.h + 2.0 >= 5.0) {
+                launch_nn_scan<2>(mode, false, ps->a.sched_local, nn_grid, ctx->stream, a);
             } else {
                 launch_nn_scan<1>(mode, false, ps->a.sched_local, nn_grid, ctx->stream, a);
             }

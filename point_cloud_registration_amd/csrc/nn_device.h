@@ -239,8 +239,7 @@ __device__ __forceinline__ int nn_ring0(const Geom<Real> &g, const PT *__restric
 #ifndef PCR_OCC_MIN_RING
 #define PCR_OCC_MIN_RING 1
 #endif
-template <typename Real> struct NNUseRowOcc { static constexpr bool value = false; };
-template <> struct NNUseRowOcc<double> { static constexpr bool value = true; };
+
 // true when ring `k` (>= 1) and everything beyond it cannot improve on `best`
 template <typename Real>
 __device__ __forceinline__ bool nn_certified(const Geom<Real> &g, const NNCell<Real> &c, int k, Real best) {
@@ -251,7 +250,7 @@ __device__ __forceinline__ bool nn_certified(const Geom<Real> &g, const NNCell<R
 
 // Rings kstart (>= 1) .. kmax.
 // (a tracking search prunes with tk->prune wherever the plain one prunes with best: PB below)
-template <typename Real, typename PT, bool STATS = false, bool TRACK = false>
+template <typename Real, typename PT, bool STATS = false, bool TRACK = false, bool OCC = false>
 __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restrict__ pts, const uint32_t *__restrict__ cs,
                                          const NNCell<Real> &c, int kstart, Real qx, Real qy, Real qz,
                                          Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr,
@@ -314,14 +313,14 @@ __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restri
                     }
                 }
             };
-            // Which rows?  Every y of the ring -- or, in the centroid search (NNUseRowOcc), for the wide rings of a far query
+            // Which rows?  Every y of the ring -- or (OCC: the centroid search when the gate spans >= 5 rings), for the rings of a far query
             // (k >= PCR_OCC_MIN_RING) only the rows with a point in the 16-cell x-blocks around the query: one 8-byte load
             // answers it for 64 rows, where the row loop spends two cell_start loads on every empty row.  Measured per
             // pass: centroid search, vplane_10m (0.5 m voxels) 1.19 -> 0.96 ms at the converged poses, ndt_10m (1 m voxels)
             // 0.62 -> 0.64; the float32 point search LOSES
             // (89-91 instead of 80 VGPRs, 5 waves/SIMD, and the bit iteration: plane_b01 +8 %, 1e8 points +10 %), so it
             // keeps the plain row loop.
-            if (!NNUseRowOcc<Real>::value) {
+            if (!OCC) {
                 for (int y = ylo; y <= yhi; ++y) do_row(y);
             } else {
                 const bool occ = g.rowocc != nullptr && k >= PCR_OCC_MIN_RING;
@@ -353,7 +352,7 @@ __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restri
 // the search then only has to look inside that radius) or (bound2, PCR_NONE, PCR_NONE).
 // TRACK: `tk` was initialised with nn_track_init(tk, bound2, mu); on return min(tk->second, tk->pmin) is a lower
 // bound on the squared distance to every target point other than the winner (to every point if there is none).
-template <typename Real, typename PT, bool STATS = false, bool SEEDED = false, bool HALO = false, bool TRACK = false>
+template <typename Real, typename PT, bool STATS = false, bool SEEDED = false, bool HALO = false, bool TRACK = false, bool OCC = false>
 __device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restrict__ pts,
                                           const uint32_t *__restrict__ cs,
                                           Real qx, Real qy, Real qz, Real bound2,
@@ -362,6 +361,6 @@ __device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restr
     if (!SEEDED) { best = bound2; bj = PCR_NONE; borig = PCR_NONE; }
     NNCell<Real> c = nn_cell<Real>(g, qx, qy, qz, bound2);
     const int kstart = nn_ring0<Real, PT, STATS, HALO, TRACK>(g, pts, cs, c, qx, qy, qz, best, bj, borig, st, tk);
-    nn_rings<Real, PT, STATS, TRACK>(g, pts, cs, c, kstart, qx, qy, qz, best, bj, borig, st, tk);
+    nn_rings<Real, PT, STATS, TRACK, OCC>(g, pts, cs, c, kstart, qx, qy, qz, best, bj, borig, st, tk);
 }
 

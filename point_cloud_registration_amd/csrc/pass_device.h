@@ -496,11 +496,11 @@ __device__ __forceinline__ void nn_point(const LinArgs &a, const PoseK &P, const
         if (track) {
             NNTrack<double> tk;
             nn_track_init<double>(tk, a.bound2_d, (double)mu);
-            nn_search<double, PtD, false, false, false, true>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz,
+            nn_search<double, PtD, false, false, false, true, VOXEL == 2>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz,
                                                              a.bound2_d, best, bj, bo, nullptr, &tk);
             lb2q = fmin(tk.second, tk.pmin);
         } else {
-            nn_search<double, PtD, false, false, false, false>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz,
+            nn_search<double, PtD, false, false, false, false, VOXEL == 2>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz,
                                                               a.bound2_d, best, bj, bo);
             lb2q = best;
         }

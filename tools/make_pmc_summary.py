@@ -34,12 +34,19 @@ def main():
             continue
         by = {}
         total = 0.0
+        # one pass = one launch of the kernel that folds (k_reduce_finalize / k_linearize_finalize); a pass runs ONE of the
+        # k_nn_scan instantiations (tile hand-out chosen per launch), so the per-pass figure weights every kernel's
+        # average by its share of the launches
+        passes = max([v["dispatches"] for k, v in f.items() if "finalize" in k] or [1])
         for k in sorted(set(f) | set(w)):
             fb = f.get(k, {}).get("kb", 0.0) * 1024 * 2          # FETCH_SIZE reads half on gfx950
             wb = w.get(k, {}).get("kb", 0.0) * 1024
-            by[k] = {"fetch_bytes": round(fb), "write_bytes": round(wb), "avg_us": f.get(k, w.get(k, {})).get("avg_us")}
-            total += fb + wb
-        summary[cfg] = {"hbm_bytes_per_pass": round(total), "by_kernel": by,
+            n = f.get(k, w.get(k, {})).get("dispatches", 0)
+            by[k] = {"fetch_bytes": round(fb), "write_bytes": round(wb), "avg_us": f.get(k, w.get(k, {})).get("avg_us"), "launches": n}
+            if "gn_update" in k:
+                continue                                          # (the trajectory align of the bench set-up, not a pass)
+            total += (fb + wb) * n / passes
+        summary[cfg] = {"hbm_bytes_per_pass": round(total), "passes": passes, "by_kernel": by,
                         "source": [f"profiles/{tag}_pmc_fetch.txt", f"profiles/{tag}_pmc_write.txt"]}
     json.dump(summary, open(os.path.join(REPO, "profiles", "pmc_summary.json"), "w"), indent=2)
     print(json.dumps(summary, indent=1)[:1500])
