@@ -484,11 +484,25 @@ def hash64(arr):
     return h.value
 
 
+_linearize_fast = None
+
+
 def linearize(target, scan, kind, T, max_dist, flags=FLAG_ICP_RR_QUIRK):
-    """One pass of the hot path -> the 29 sums (see include/pcr.h)."""
-    out = np.zeros(29)
-    T = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
-    check(lib().pcr_linearize(target.handle, scan.handle, int(kind), T, float(max_dist), int(flags), out))
+    """One pass of the hot path -> the 29 sums (see include/pcr.h).
+
+    Called once per Gauss-Newton iteration: the binding goes through a second ctypes prototype with plain pointer
+    arguments (``numpy.ctypeslib.ndpointer`` re-validates dtype / flags / shape of every array on every call, a few
+    microseconds against a 50-150 us pass); the arrays are made float64 C-contiguous right here."""
+    global _linearize_fast
+    if _linearize_fast is None:
+        proto = C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_int, _vp, C.c_double, C.c_uint, _vp)
+        _linearize_fast = C.cast(lib().pcr_linearize, proto)
+    out = np.empty(29)
+    if not (isinstance(T, np.ndarray) and T.dtype == np.float64 and T.flags.c_contiguous and T.size == 16):
+        T = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+    st = _linearize_fast(target.handle, scan.handle, kind, T.ctypes.data, max_dist, flags, out.ctypes.data)
+    if st != PCR_OK:
+        check(st)
     return out
 
 

@@ -558,9 +558,12 @@ __device__ __forceinline__ void finalize_emit(const FinArgs &f, const double *to
         if (v) atomicAdd(&listed, v);
         __syncthreads();
     }
+    // the 29-vector is assembled in LDS by one thread, then stored by 32: to HBM and, in parallel, to pinned host
+    // memory (round 2 had thread 0 store 29 values to HBM and READ THEM BACK for 31 stores to the host, one after the other)
+    __shared__ double o_sh[32];
     if (threadIdx.x == 0) {
         if (f.kind != PCR_ICP) {
-            for (int i = 0; i < 29; ++i) f.out[i] = tot[i];
+            for (int i = 0; i < 29; ++i) o_sh[i] = tot[i];
         } else {
             // H_ll = M I (icp.py:43); H_lr = -R skew(sum p) (icp.py:44); H_rr from the second
             // moments (math_tools.py:44-58)
@@ -580,17 +583,23 @@ __device__ __forceinline__ void finalize_emit(const FinArgs &f, const double *to
             H[3][3] = yy + zz; H[3][4] = -xy; H[3][5] = -xz;
             H[4][4] = xx + zz; H[4][5] = -yz; H[5][5] = xx + yy;
             int p = 0;
-            for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) f.out[p++] = H[i][j];
-            for (int i = 0; i < 3; ++i) { f.out[21 + i] = tot[10 + i]; f.out[24 + i] = tot[13 + i]; }
-            f.out[27] = tot[16]; f.out[28] = cnt;
+            for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) o_sh[p++] = H[i][j];
+            for (int i = 0; i < 3; ++i) { o_sh[21 + i] = tot[10 + i]; o_sh[24 + i] = tot[13 + i]; }
+            o_sh[27] = tot[16]; o_sh[28] = cnt;
         }
-        f.out[29] = mode == PCR_NN_LIST ? (double)listed : 0.0; f.out[30] = (double)mode; f.out[31] = 0;
+        o_sh[29] = mode == PCR_NN_LIST ? (double)listed : 0.0; o_sh[30] = (double)mode; o_sh[31] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const double v = o_sh[threadIdx.x];
+        f.out[threadIdx.x] = v;
         if (f.host_out) {
-            for (int i = 0; i < 31; ++i) f.host_out[i] = f.out[i];
+            f.host_out[threadIdx.x] = v;          // (the 32nd double of the pinned block is unused padding: the flag lives at [32])
             __threadfence_system();
-            *f.host_flag = f.seq;
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0 && f.host_out) *f.host_flag = f.seq;
 }
 
 // The fold of the per-block partial sums INSIDE the producing kernel (no separate k_finalize launch: ~10 us
