@@ -250,8 +250,78 @@ __device__ __forceinline__ bool nn_certified(const Geom<Real> &g, const NNCell<R
 
 // Rings kstart (>= 1) .. kmax.
 // (a tracking search prunes with tk->prune wherever the plain one prunes with best: PB below)
-template <typename Real, typename PT, bool STATS = false, bool TRACK = false, bool OCC = false>
+template <typename Real, typename PT, bool STATS = false, bool TRACK = false>
 __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restrict__ pts, const uint32_t *__restrict__ cs,
+                                         const NNCell<Real> &c, int kstart, Real qx, Real qy, Real qz,
+                                         Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr,
+                                         NNTrack<Real> *tk = nullptr) {
+#define PB (TRACK ? tk->prune : best)
+    typedef RealTraits<Real> RT;
+    const Real lim = (Real)1.0e9;
+    const int cx = c.cx, cy = c.cy, cz = c.cz;
+    const Real fx = c.fx, fy = c.fy, fz = c.fz;
+    const uint32_t unx = (uint32_t)g.nx, plane = (uint32_t)g.ny * (uint32_t)g.nx;   // ncells < 2^32
+    for (int k = kstart; k <= c.kmax; ++k) {
+        if (nn_certified<Real>(g, c, k, PB)) break;
+        if (STATS) st->rings++;
+        const int zlo = max(cz - k, 0), zhi = min(cz + k, g.nz - 1);
+        const int ylo = max(cy - k, 0), yhi = min(cy + k, g.ny - 1);
+        const int xlo = max(cx - k, 0), xhi = min(cx + k, g.nx - 1);
+        const int xa = cx - k, xb = cx + k;
+        const bool xa_in = xa >= 0 && xa < g.nx, xb_in = xb >= 0 && xb < g.nx;
+        Real dxa = fmax((Real)(k - 1) * g.h + fx - g.slack, (Real)0), dxb = fmax((Real)k * g.h - fx - g.slack, (Real)0);
+        dxa *= dxa; dxb *= dxb;
+        for (int z = zlo; z <= zhi; ++z) {
+            const int dzc = z - cz;
+            Real dzm = dzc == 0 ? (Real)0 : (dzc > 0 ? (Real)dzc * g.h - fz : (Real)(-dzc - 1) * g.h + fz);
+            dzm = fmax(dzm - g.slack, (Real)0);
+            const Real dz2 = dzm * dzm;
+            if (dz2 > PB) continue;
+            const bool zshell = (dzc == k) || (dzc == -k);
+            uint32_t row = (uint32_t)z * plane + (uint32_t)ylo * unx;
+            for (int y = ylo; y <= yhi; ++y, row += unx) {
+                const int dyc = y - cy;
+                Real dym = dyc == 0 ? (Real)0 : (dyc > 0 ? (Real)dyc * g.h - fy : (Real)(-dyc - 1) * g.h + fy);
+                dym = fmax(dym - g.slack, (Real)0);
+                const Real dyz2 = dz2 + dym * dym;
+                if (dyz2 > PB) { if (STATS) st->rows_pruned++; continue; }
+                if (zshell || dyc == k || dyc == -k) {
+                    int xl = xlo, xh = xhi;
+                    if (PB < RT::inf()) {                   // clip the row to the remaining budget
+                        // approximate sqrt is fine here: the clip only has to be conservative
+                        const Real xr = RT::sqrt_fast(PB - dyz2) * (Real)1.000002 + g.slack;
+                        const Real a = (qx - xr - g.ox) * g.inv_h, b = (qx + xr - g.ox) * g.inv_h;
+                        if (a > (Real)xl) xl = (int)RT::floor_(fmin(a, lim));
+                        if (b < (Real)xh) xh = (int)RT::floor_(fmax(b, -lim));
+                    }
+                    if (xl <= xh) {
+                        const uint32_t s_ = cs[row + (uint32_t)xl] & g.cs_mask, e_ = cs[row + (uint32_t)xh + 1u] & g.cs_mask;
+                        if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
+                        nn_scan_range<Real, PT, TRACK>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
+                    }
+                } else {                                    // interior row of the ring: its two end cells
+                    if (xa_in && dyz2 + dxa <= PB) {
+                        const uint32_t s_ = cs[row + (uint32_t)xa] & g.cs_mask, e_ = cs[row + (uint32_t)xa + 1u] & g.cs_mask;
+                        if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
+                        nn_scan_range<Real, PT, TRACK>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
+                    }
+                    if (xb_in && dyz2 + dxb <= PB) {
+                        const uint32_t s_ = cs[row + (uint32_t)xb] & g.cs_mask, e_ = cs[row + (uint32_t)xb + 1u] & g.cs_mask;
+                        if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
+                        nn_scan_range<Real, PT, TRACK>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
+                    }
+                }
+            }
+        }
+    }
+#undef PB
+}
+
+// The same rings with the rows of a slab taken from the row-occupancy bitmap (Geom::rowocc): the centroid search when
+// the gate spans >= 5 rings (kernels.hip: k_nn_scan<VOXEL = 2>).  A separate function on purpose: routing the plain
+// search through the shared row body (a lambda) cost the 1e8-point search 5-13 % (74.5 / 80.5 vs 70.9 ms per 26 passes).
+template <typename Real, typename PT, bool STATS = false, bool TRACK = false>
+__device__ __forceinline__ void nn_rings_occ(const Geom<Real> &g, const PT *__restrict__ pts, const uint32_t *__restrict__ cs,
                                          const NNCell<Real> &c, int kstart, Real qx, Real qy, Real qz,
                                          Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr,
                                          NNTrack<Real> *tk = nullptr) {
@@ -320,9 +390,7 @@ __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restri
             // 0.62 -> 0.64; the float32 point search LOSES
             // (89-91 instead of 80 VGPRs, 5 waves/SIMD, and the bit iteration: plane_b01 +8 %, 1e8 points +10 %), so it
             // keeps the plain row loop.
-            if (!OCC) {
-                for (int y = ylo; y <= yhi; ++y) do_row(y);
-            } else {
+            {
                 const bool occ = g.rowocc != nullptr && k >= PCR_OCC_MIN_RING;
                 const int xb0 = xlo >> 4, xb1 = xhi >> 4;
                 for (int wy = ylo >> 6; wy <= (yhi >> 6); ++wy) {
@@ -361,6 +429,7 @@ __device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restr
     if (!SEEDED) { best = bound2; bj = PCR_NONE; borig = PCR_NONE; }
     NNCell<Real> c = nn_cell<Real>(g, qx, qy, qz, bound2);
     const int kstart = nn_ring0<Real, PT, STATS, HALO, TRACK>(g, pts, cs, c, qx, qy, qz, best, bj, borig, st, tk);
-    nn_rings<Real, PT, STATS, TRACK, OCC>(g, pts, cs, c, kstart, qx, qy, qz, best, bj, borig, st, tk);
+    if (OCC) nn_rings_occ<Real, PT, STATS, TRACK>(g, pts, cs, c, kstart, qx, qy, qz, best, bj, borig, st, tk);
+    else nn_rings<Real, PT, STATS, TRACK>(g, pts, cs, c, kstart, qx, qy, qz, best, bj, borig, st, tk);
 }
 
