@@ -175,7 +175,9 @@ PCR_API pcr_status pcr_knn_query(pcr_target *t, const float *q, int64_t m, int k
  * context's stream; pcr_profile_read drains them (synchronises) and reports per-kernel
  * launch count and total milliseconds since the last reset.  on = n > 1 brackets only every
  * n-th pass (an event pair costs a few microseconds of stream time: sampling keeps a timed
- * region honest); on = 1 every pass; 0 off.                                                 */
+ * region honest); on = 1 every pass; 0 off.  pcr_align's device-resident loop keeps up to two
+ * iterations queued beyond the one that converges: those launches return at once but are
+ * bracketed like the others, so per-kernel averages taken over an align include them.        */
 enum { PCR_K_LINEARIZE = 0, PCR_K_FINALIZE = 1, PCR_K_NN = 2, PCR_K_REDUCE = 3, PCR_K_ALLREDUCE = 4, PCR_K_CERTIFY = 5, PCR_K_COUNT = 6 };
 PCR_API pcr_status pcr_profile_enable(pcr_context *ctx, int on);
 PCR_API pcr_status pcr_profile_reset(pcr_context *ctx);
