@@ -142,32 +142,45 @@ __device__ __forceinline__ void acc_icp(double *acc, const PoseK &a, unsigned fl
 
 __device__ __forceinline__ void acc_ndt(double *acc, const PoseK &a, double x, double y, double z,
                                         const double *__restrict__ c6, double d0, double d1, double d2) {
-    // J = [I, -R skew(p)] (ndt.py:40); C symmetric inverse covariance
+    // J = [I, A] with A = -R skew(p) (ndt.py:40); C symmetric inverse covariance.  The identity block is exploited by
+    // hand: H_ll = C, H_lr = C A, H_rr = A^T (C A), g = [C d, A^T (C d)] -- the generic J^T C J spends 60 % of its
+    // multiplications on exact ones and zeros, which the compiler may not drop (0 * x is not 0 for a NaN).  Every
+    // non-trivial entry is evaluated in the order the generic form used ((p0 + p1) + p2), so the sums are bit-identical
+    // to round 2's for finite inputs.
     const double C[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
-    double J[3][6];
+    double A[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const double ri0 = a.R[3 * i], ri1 = a.R[3 * i + 1], ri2 = a.R[3 * i + 2];
-        J[i][0] = i == 0; J[i][1] = i == 1; J[i][2] = i == 2;
         // -(R S) with S = [[0,-z,y],[z,0,-x],[-y,x,0]]
-        J[i][3] = -(ri1 * z - ri2 * y);
-        J[i][4] = -(-ri0 * z + ri2 * x);
-        J[i][5] = -(ri0 * y - ri1 * x);
+        A[i][0] = -(ri1 * z - ri2 * y);
+        A[i][1] = -(-ri0 * z + ri2 * x);
+        A[i][2] = -(ri0 * y - ri1 * x);
     }
-    double CJ[3][6], Cd[3];
+    double CA[3][3], Cd[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         Cd[i] = C[i][0] * d0 + C[i][1] * d1 + C[i][2] * d2;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) CJ[i][j] = C[i][0] * J[0][j] + C[i][1] * J[1][j] + C[i][2] * J[2][j];
+        for (int j = 0; j < 3; ++j) CA[i][j] = C[i][0] * A[0][j] + C[i][1] * A[1][j] + C[i][2] * A[2][j];
     }
+    // upper triangle, row-major: rows 0..2 = [C (upper part) | C A], rows 3..5 = A^T (C A) (upper part)
     int p = 0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 3; ++i) {
 #pragma unroll
-        for (int j = i; j < 6; ++j) { acc[p] += J[0][i] * CJ[0][j] + J[1][i] * CJ[1][j] + J[2][i] * CJ[2][j]; ++p; }
+        for (int j = i; j < 3; ++j) { acc[p] += C[i][j]; ++p; }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) acc[21 + i] += J[0][i] * Cd[0] + J[1][i] * Cd[1] + J[2][i] * Cd[2];
+        for (int j = 0; j < 3; ++j) { acc[p] += CA[i][j]; ++p; }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i; j < 3; ++j) { acc[p] += A[0][i] * CA[0][j] + A[1][i] * CA[1][j] + A[2][i] * CA[2][j]; ++p; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[21 + i] += Cd[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[24 + i] += A[0][i] * Cd[0] + A[1][i] * Cd[1] + A[2][i] * Cd[2];
     acc[27] += d0 * Cd[0] + d1 * Cd[1] + d2 * Cd[2];
     acc[28] += 1.0;
 }
