@@ -160,3 +160,112 @@ def test_unpack29_and_sharding():
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         sizes = [hi - lo for lo, hi in spans]
         assert max(sizes) - min(sizes) <= 1
+
+
+# ----------------------------------------------------------------------------- round 3: seam hash, reuse policy
+def test_hash64_content_hash():
+    """pcr_hash64 (no GPU needed): deterministic, sensitive to one bit anywhere, independent of the number of
+    pool threads (fixed 256 KiB chunks folded in order), and the class seam's digest separates C / F layouts."""
+    import os
+    import subprocess
+    import sys
+    rng = np.random.default_rng(0)
+    a = rng.random((300_000, 3)).astype(np.float32)                 # 3.6 MB: 14 chunks, the parallel path
+    h = _capi.hash64(a)
+    assert h == _capi.hash64(a.copy()) and h == _capi.hash64(a)
+    for idx in ((0, 0), (123_456, 1), (299_999, 2)):
+        b = a.copy()
+        b[idx] = np.nextafter(b[idx], np.float32(2.0))
+        assert _capi.hash64(b) != h
+    assert _capi.hash64(a[:1000].copy()) != _capi.hash64(a[:1001].copy())
+    assert _capi.hash64(np.zeros((0, 3), np.float32)) == _capi.hash64(np.zeros((0, 3), np.float32))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "from point_cloud_registration_amd import _capi\n"
+            "a = np.random.default_rng(0).random((300000, 3)).astype(np.float32); print(_capi.hash64(a))\n"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    for threads in ("0", "3"):
+        out = subprocess.run([sys.executable, "-c", code], env={**os.environ, "PCR_HASH_THREADS": threads},
+                             capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr[-500:]
+        assert int(out.stdout.strip().splitlines()[-1]) == h, threads
+    # the class seam: an F-ordered view (what (R @ P.T).T yields) is hashed in place, and differs from the C copy's key
+    f = np.asfortranarray(a)
+    dig = pcr.ICP._digest
+    assert dig(f) == dig(np.asfortranarray(a.copy())) and dig(f) != dig(a)
+    g = f.copy(order="F"); g[7, 1] += 1.0
+    assert dig(g) != dig(f)
+
+
+def test_reuse_policy_restated():
+    """gn_choose_nn_mode / gn_typical_motion (csrc/gn_math.h) restated: the automatic policy never starts tracking on a
+    quadratically converging run, keeps going once tracking, and the typical displacement is what it says."""
+    def typical_motion(Ta, Tb, c, e):
+        pts = [np.array(c, float)]
+        for ax in range(3):
+            for sgn in (-1, 1):
+                p = np.array(c, float); p[ax] += sgn * e[ax]; pts.append(p)
+        return float(np.mean([np.linalg.norm((Tb[:3, :3] @ p + Tb[:3, 3]) - (Ta[:3, :3] @ p + Ta[:3, 3])) for p in pts]))
+
+    def choose(reuse, have_prev, track_valid, motion, prev_motion, tau_len):
+        if reuse == 0 or not have_prev:
+            return 0
+        if reuse == 2:
+            return 2 if track_valid else 1
+        if not (motion < tau_len):
+            return 0
+        if track_valid:
+            return 2
+        if motion == 0.0:
+            return 1
+        if 0.0 <= prev_motion < 8.0 * tau_len and motion > 0.3 * prev_motion:
+            return 1
+        return 0
+
+    T1 = np.eye(4); T2 = np.eye(4); T2[:3, 3] = [0.003, 0.0, 0.004]
+    assert abs(typical_motion(T1, T2, (0, 0, 0), (60, 30, 10)) - 0.005) < 1e-12       # a pure translation moves every probe alike
+    R = mt.expSO3(np.array([0.0, 0.0, 1e-3])); T3 = np.eye(4); T3[:3, :3] = R
+    m = typical_motion(T1, T3, (0, 0, 0), (60, 30, 10))
+    assert 0.02 < m < 0.03                                                            # 1 mrad about z: 0 / 60 mm / 30 mm / 0 at the probes
+    tau = 0.0125 * 0.405
+    # plane_b01's measured steps (mm): 428, 236, 117, 18 -> never below tau, never tracking
+    prev = -1.0
+    for step in (0.428, 0.236, 0.117, 0.018):
+        assert choose(1, True, False, step, prev, tau) == 0
+        prev = step
+    # a slow sub-millimetre tail starts tracking, then lists; a jump drops back to the plain search
+    assert choose(1, True, False, 0.004, 0.006, tau) == 1 and choose(1, True, True, 0.003, 0.004, tau) == 2
+    assert choose(1, True, True, 0.2, 0.003, tau) == 0 and choose(1, True, False, 0.0, 0.2, tau) == 1
+    assert choose(1, True, False, 0.001, 0.02, tau) == 0                              # quadratic convergence: the loop ends first
+    assert choose(0, True, True, 0.0, 0.0, tau) == 0 and choose(2, True, False, 1.0, 1.0, tau) == 1
+    # ... and the C functions themselves (csrc/gn_math.h compiles as plain host C++) agree with the restatement
+    import os
+    import subprocess
+    import tempfile
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = r"""
+#include <stdio.h>
+#include "gn_math.h"
+int main() {
+    double Ta[16] = {1,0,0,0, 0,1,0,0, 0,0,1,0, 0,0,0,1}, Tb[16];
+    for (int i = 0; i < 16; ++i) Tb[i] = Ta[i];
+    Tb[3] = 0.003; Tb[11] = 0.004;
+    const float c[3] = {0, 0, 0}, e[3] = {60, 30, 10};
+    printf("%.17g\n", gn_typical_motion(Ta, Tb, c, e));
+    const double tau = 0.0125 * 0.405;
+    const double cases[][5] = {{1,1,0,0.428,-1}, {1,1,0,0.018,0.117}, {1,1,0,0.004,0.006}, {1,1,1,0.003,0.004}, {1,1,1,0.2,0.003},
+                               {1,1,0,0.0,0.2}, {1,1,0,0.001,0.02}, {0,1,1,0,0}, {2,1,0,1,1}, {2,1,1,1,1}, {1,0,1,0,0}};
+    for (auto &k : cases) printf("%d\n", gn_choose_nn_mode((int)k[0], (int)k[1], (int)k[2], k[3], k[4], tau));
+    return 0;
+}
+"""
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.cpp"), "w").write(src)
+        subprocess.run(["g++", "-O1", "-I", os.path.join(repo, "point_cloud_registration_amd", "csrc"), os.path.join(d, "t.cpp"),
+                        "-o", os.path.join(d, "t")], check=True, capture_output=True)
+        out = subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split()
+    assert abs(float(out[0]) - 0.005) < 1e-12
+    want = [choose(1, True, False, 0.428, -1, tau), choose(1, True, False, 0.018, 0.117, tau), choose(1, True, False, 0.004, 0.006, tau),
+            choose(1, True, True, 0.003, 0.004, tau), choose(1, True, True, 0.2, 0.003, tau), choose(1, True, False, 0.0, 0.2, tau),
+            choose(1, True, False, 0.001, 0.02, tau), choose(0, True, True, 0, 0, tau), choose(2, True, False, 1, 1, tau),
+            choose(2, True, True, 1, 1, tau), choose(1, False, True, 0, 0, tau)]
+    assert [int(v) for v in out[1:]] == want
