@@ -138,21 +138,24 @@ __device__ __forceinline__ void nn_track_refresh(NNTrack<Real> &tk, Real best) {
 // A batch may run up to PCR_NN_BATCH-1 records past the end of the range: those are real points of the following cells
 // (testing an extra true candidate can only help), and the array carries PCR_PTS_PAD sentinel
 // records at +inf behind its last point, which never win a comparison.
-#define PCR_PTS_PAD 8
+#define PCR_PTS_PAD 16
 #ifndef PCR_NN_BATCH
-#define PCR_NN_BATCH 4   // measured: 8 costs occupancy (101 VGPR) and is slower except for tiny scans
+#define PCR_NN_BATCH 4   // measured: 8 costs occupancy (101 VGPR) and is slower -- except for small scans, where a pass is a
+#endif                   // chain of dependent round trips and a batch is one of them: the fused small-scan kernel uses
+#ifndef PCR_NN_BATCH_SMALL   // PCR_NN_BATCH_SMALL (100 k-point ICP harness scan 42.3 -> 38.4 us per pass with 8)
+#define PCR_NN_BATCH_SMALL 8
 #endif
-template <typename Real, typename PT, bool TRACK = false>
+template <typename Real, typename PT, bool TRACK = false, int B = PCR_NN_BATCH>
 __device__ __forceinline__ void nn_scan_range(const PT *__restrict__ pts, uint32_t s, uint32_t e,
                                               Real qx, Real qy, Real qz, Real &best, uint32_t &bj, uint32_t &borig,
                                               NNTrack<Real> *tk = nullptr) {
-    for (uint32_t j = s; j < e; j += PCR_NN_BATCH) {
+    for (uint32_t j = s; j < e; j += B) {
         const PT *__restrict__ b = pts + j;
-        PT p[PCR_NN_BATCH];
+        PT p[B];
 #pragma unroll
-        for (int u = 0; u < PCR_NN_BATCH; ++u) p[u] = b[u];
+        for (int u = 0; u < B; ++u) p[u] = b[u];
 #pragma unroll
-        for (int u = 0; u < PCR_NN_BATCH; ++u) nn_test<Real, PT, TRACK>(p[u], j + u, qx, qy, qz, best, bj, borig, tk);
+        for (int u = 0; u < B; ++u) nn_test<Real, PT, TRACK>(p[u], j + u, qx, qy, qz, best, bj, borig, tk);
     }
     if (TRACK) nn_track_refresh<Real>(*tk, best);
 }
@@ -200,7 +203,7 @@ __device__ __forceinline__ NNCell<Real> nn_cell(const Geom<Real> &g, Real qx, Re
 // nearly converged query (residual << halo) is certified by ring 0 alone and never enters the ring
 // loop: without the halo the ~8 % of lanes that sit closer to a face than to their match drag their
 // whole wave through ring 1 (measured: 75 % of the wave time at the converged pose).
-template <typename Real, typename PT, bool STATS = false, bool HALO = false, bool TRACK = false>
+template <typename Real, typename PT, bool STATS = false, bool HALO = false, bool TRACK = false, int B = PCR_NN_BATCH>
 __device__ __forceinline__ int nn_ring0(const Geom<Real> &g, const PT *__restrict__ pts, const uint32_t *__restrict__ cs,
                                         NNCell<Real> &c, Real qx, Real qy, Real qz,
                                         Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr,
@@ -218,11 +221,11 @@ __device__ __forceinline__ int nn_ring0(const Geom<Real> &g, const PT *__restric
             // the extended list holds COPIES: track the position in it, then translate the winner to its
             // cell-sorted index (j_h is laid out like the lists, so neighbouring queries share its lines)
             uint32_t ej = PCR_NONE;
-            nn_scan_range<Real, PT, TRACK>((const PT *)g.pts_h, s_, e_, qx, qy, qz, best, ej, borig, tk);
+            nn_scan_range<Real, PT, TRACK, B>((const PT *)g.pts_h, s_, e_, qx, qy, qz, best, ej, borig, tk);
             if (ej != PCR_NONE) bj = g.j_h[ej];
             c.reach0 = g.halo;
         } else {
-            nn_scan_range<Real, PT, TRACK>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
+            nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
         }
         return 1;
     }
@@ -250,7 +253,7 @@ __device__ __forceinline__ bool nn_certified(const Geom<Real> &g, const NNCell<R
 
 // Rings kstart (>= 1) .. kmax.
 // (a tracking search prunes with tk->prune wherever the plain one prunes with best: PB below)
-template <typename Real, typename PT, bool STATS = false, bool TRACK = false>
+template <typename Real, typename PT, bool STATS = false, bool TRACK = false, int B = PCR_NN_BATCH>
 __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restrict__ pts, const uint32_t *__restrict__ cs,
                                          const NNCell<Real> &c, int kstart, Real qx, Real qy, Real qz,
                                          Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr,
@@ -297,18 +300,18 @@ __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restri
                     if (xl <= xh) {
                         const uint32_t s_ = cs[row + (uint32_t)xl] & g.cs_mask, e_ = cs[row + (uint32_t)xh + 1u] & g.cs_mask;
                         if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-                        nn_scan_range<Real, PT, TRACK>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
+                        nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
                     }
                 } else {                                    // interior row of the ring: its two end cells
                     if (xa_in && dyz2 + dxa <= PB) {
                         const uint32_t s_ = cs[row + (uint32_t)xa] & g.cs_mask, e_ = cs[row + (uint32_t)xa + 1u] & g.cs_mask;
                         if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-                        nn_scan_range<Real, PT, TRACK>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
+                        nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
                     }
                     if (xb_in && dyz2 + dxb <= PB) {
                         const uint32_t s_ = cs[row + (uint32_t)xb] & g.cs_mask, e_ = cs[row + (uint32_t)xb + 1u] & g.cs_mask;
                         if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-                        nn_scan_range<Real, PT, TRACK>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
+                        nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
                     }
                 }
             }
@@ -420,7 +423,8 @@ __device__ __forceinline__ void nn_rings_occ(const Geom<Real> &g, const PT *__re
 // the search then only has to look inside that radius) or (bound2, PCR_NONE, PCR_NONE).
 // TRACK: `tk` was initialised with nn_track_init(tk, bound2, mu); on return min(tk->second, tk->pmin) is a lower
 // bound on the squared distance to every target point other than the winner (to every point if there is none).
-template <typename Real, typename PT, bool STATS = false, bool SEEDED = false, bool HALO = false, bool TRACK = false, bool OCC = false>
+template <typename Real, typename PT, bool STATS = false, bool SEEDED = false, bool HALO = false, bool TRACK = false, bool OCC = false,
+          int B = PCR_NN_BATCH>
 __device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restrict__ pts,
                                           const uint32_t *__restrict__ cs,
                                           Real qx, Real qy, Real qz, Real bound2,
@@ -428,8 +432,8 @@ __device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restr
                                           NNTrack<Real> *tk = nullptr) {
     if (!SEEDED) { best = bound2; bj = PCR_NONE; borig = PCR_NONE; }
     NNCell<Real> c = nn_cell<Real>(g, qx, qy, qz, bound2);
-    const int kstart = nn_ring0<Real, PT, STATS, HALO, TRACK>(g, pts, cs, c, qx, qy, qz, best, bj, borig, st, tk);
+    const int kstart = nn_ring0<Real, PT, STATS, HALO, TRACK, B>(g, pts, cs, c, qx, qy, qz, best, bj, borig, st, tk);
     if (OCC) nn_rings_occ<Real, PT, STATS, TRACK>(g, pts, cs, c, kstart, qx, qy, qz, best, bj, borig, st, tk);
-    else nn_rings<Real, PT, STATS, TRACK>(g, pts, cs, c, kstart, qx, qy, qz, best, bj, borig, st, tk);
+    else nn_rings<Real, PT, STATS, TRACK, B>(g, pts, cs, c, kstart, qx, qy, qz, best, bj, borig, st, tk);
 }
 

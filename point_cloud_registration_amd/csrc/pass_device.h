@@ -362,11 +362,13 @@ __device__ __forceinline__ void linearize_body(const LinArgs &a, const PoseK &P,
         bool ok;
         if (KIND == PCR_ICP || KIND == PCR_PLANE) {
             float best;
-            nn_search<float, PtF, false, false, HALO != 0>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
+            nn_search<float, PtF, false, false, HALO != 0, false, false, PCR_NN_BATCH_SMALL>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f,
+                                                                                          best, bj, bo);
             ok = bj != PCR_NONE && __builtin_sqrtf(best) < a.md_f;                 // icp.py:34 strict gate
         } else {
             double best;
-            nn_search<double, PtD>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz, a.bound2_d, best, bj, bo);
+            nn_search<double, PtD, false, false, false, false, false, PCR_NN_BATCH_SMALL>(a.gd, a.means, a.cell_start, (double)tx, (double)ty,
+                                                                                       (double)tz, a.bound2_d, best, bj, bo);
             ok = bj != PCR_NONE && __builtin_sqrt(best) < a.md_d;                 // voxelized_plane_icp.py:38
         }
         if (ok) accumulate<KIND, false>(acc, a, P, bj, x, y, z, tx, ty, tz);
