@@ -22,6 +22,7 @@ FLAG_ICP_RR_QUIRK = 1
 FLAG_NO_SCAN_SORT = 2
 FLAG_LOCAL_ONLY = 4          # no all-reduce even when the context has a communicator
 FLAG_HOST_LOOP = 8           # pcr_align: host-driven loop instead of the device-resident one
+FLAG_DEVICE_LOOP = 16        # pcr_align: device-resident loop even for small scans (where the host-driven one is picked)
 K_LINEARIZE, K_FINALIZE, K_NN, K_REDUCE, K_ALLREDUCE, K_CERTIFY, K_COUNT = 0, 1, 2, 3, 4, 5, 6
 KERNEL_NAMES = ("linearize", "finalize", "nn", "reduce", "allreduce", "certify")
 NN_FULL, NN_TRACK, NN_LIST = 0, 1, 2      # what the search of a pass did (certified reuse, include/pcr.h)

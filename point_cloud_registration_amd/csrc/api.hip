@@ -586,8 +586,12 @@ extern "C" pcr_status pcr_align(pcr_target *t, pcr_scan *s, int kind, const doub
                                 double *trace_or_null) {
     PCR_REQUIRE(t && s && T_init && T_out, "NULL argument");
     CtxScope scope(t->ctx);
-    // (certified reuse runs on host-driven passes; forced on, the loop is driven from the host)
-    if ((flags & PCR_FLAG_HOST_LOOP) || t->ctx->reuse == 2)
+    // (certified reuse runs on host-driven passes; forced on, the loop is driven from the host.  Small scans on one GPU:
+    // the zero-copy hand-off makes the host-driven iteration cheaper than the device-resident one -- one kernel either
+    // way, but the step costs ~3 us on one GPU thread against < 1 us on the host)
+    const bool use_comm = t->ctx->comm != nullptr && !(flags & PCR_FLAG_LOCAL_ONLY);
+    const bool small_host = !(flags & PCR_FLAG_DEVICE_LOOP) && !use_comm && pcr_pass_is_fused(t->ctx, s);
+    if ((flags & PCR_FLAG_HOST_LOOP) || t->ctx->reuse == 2 || small_host)
         return align_host_loop(t, s, kind, T_init, max_iter, tol, max_dist, flags, T_out, iterations, trace_or_null);
     return pcr_run_align(t, s, kind, T_init, max_iter, tol, max_dist, flags, T_out, iterations, trace_or_null);
 }

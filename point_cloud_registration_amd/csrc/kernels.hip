@@ -283,12 +283,16 @@ __global__ void __launch_bounds__(256) k_reduce_finalize(const LinArgs a, const 
     for (int i = 0; i < 32; ++i) acc[i] = 0.0;
     const TileIter it(a);
     reduce_stream<KIND>(acc, a, P, it.base, it.end, it.stride);
-    ticket_fold_emit(acc, a, f);
+    (void)ticket_fold_emit(acc, a, f);
     // (the Gauss-Newton step is NOT inlined here: its straight-line float64 code needs 136 VGPRs, which
     // would cap this streaming kernel at 3 blocks per CU; k_gn_update runs it as a 1-wave launch)
 }
 
-template <int KIND, int HALO>
+// GN (device-resident loop on one GPU): the block that emits also takes the Gauss-Newton step.  This kernel runs one
+// tile per wave at 129-191 VGPRs anyway, so -- unlike in the streaming reduce kernel -- the step's registers cost no
+// occupancy, and the iteration saves the k_gn_update launch (~8 us of a 46 us iteration on a 100 k-point scan).  Every
+// other block read the pose before it contributed its ticket, so rewriting it here races with nothing.
+template <int KIND, int HALO, int GN>
 __global__ void __launch_bounds__(256) k_linearize_finalize(const LinArgs a, const FinArgs f) {
     PoseK P;
     if (!load_pose<true>(a, P)) return;
@@ -296,7 +300,11 @@ __global__ void __launch_bounds__(256) k_linearize_finalize(const LinArgs a, con
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = 0.0;
     linearize_body<KIND, HALO>(a, P, acc);
-    ticket_fold_emit(acc, a, f);
+    const bool last = ticket_fold_emit(acc, a, f);
+    if (GN && last && threadIdx.x == 0 && f.pose->done == PCR_LOOP_RUNNING) {
+        double A[6][7];
+        gn_update(f, A);
+    }
 }
 
 // after the RCCL all-reduce: hand the 29 doubles to the host the same zero-copy way k_finalize does
@@ -377,10 +385,16 @@ struct Pass {
     FinArgs f;
     bool one_kernel;     // fused search + reduce kernel (variant 0, or variant 2 on a small scan)
     bool fused_fin;      // the fold of the block partials inside the producing kernel instead of k_finalize
+    bool gn_inline;      // device-resident loop, fused kernel, one GPU: the Gauss-Newton step runs inside k_linearize_finalize
     double motion;       // typical displacement of the scan since the previous pass over it (host-driven passes; -1 unknown)
     int nn_mode;         // PCR_NN_FULL / TRACK / LIST
     bool reuse_ready;    // the scan has the buffers of the certified-reuse path
 };
+
+bool pcr_pass_is_fused(const pcr_context *ctx, const pcr_scan *s) {
+    if (ctx->variant == 2) return s->n <= (int64_t)ctx->num_cu * 1024;   // measured crossover: 262 k - 350 k points on 256 CUs
+    return ctx->variant == 0;
+}
 
 static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, double max_dist, unsigned flags) {
     pcr_context *ctx = t->ctx;
@@ -402,8 +416,7 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
     PCR_TRY(pcr_ensure_scratch(ctx, s->n));
     // one fused kernel or search + reduce?  variant 2 (default) decides by size: a small scan is latency-bound
     // and runs fused (tools/variant_crossover.py: 100 k points 74 vs 80 us per pass, 300 k 97 vs 92, 1.06 M 190 vs 151)
-    bool one_kernel = ctx->variant == 0;
-    if (ctx->variant == 2) one_kernel = s->n <= (int64_t)ctx->num_cu * 1024;   // measured crossover: 200 k - 300 k points on 256 CUs
+    const bool one_kernel = pcr_pass_is_fused(ctx, s);
     if (!one_kernel && !s->nn_j) {
         HIP_TRY(pcr_malloc_retry((void **)&s->nn_j, sizeof(uint32_t) * (size_t)(s->n > 0 ? s->n : 1)));
         s->nn_serial = 0;
@@ -454,6 +467,7 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
     ps->fused_fin = ctx->fuse_finalize;
     ps->nn_mode = PCR_NN_FULL;
     ps->motion = -1.0;
+    ps->gn_inline = false;
     FinArgs &f = ps->f;
     memset(&f, 0, sizeof f);
     for (int i = 0; i < 3; ++i) { f.bb_c[i] = s->bb_c[i]; f.bb_e[i] = s->bb_e[i]; }
@@ -523,8 +537,11 @@ static pcr_status pass_enqueue(Pass *ps) {
         RoctxRange range("pcr:linearize");
         const bool halo = !ps->t->is_voxel && ps->t->cs_h != nullptr;
 #define PCR_LIN_CASE(K)                                                                                         \
-        if (halo) hipLaunchKernelGGL((k_linearize_finalize<K, 1>), grid, block, 0, ctx->stream, a, ps->f);      \
-        else hipLaunchKernelGGL((k_linearize_finalize<K, 0>), grid, block, 0, ctx->stream, a, ps->f);
+        if (ps->gn_inline) {                                                                                    \
+            if (halo) hipLaunchKernelGGL((k_linearize_finalize<K, 1, 1>), grid, block, 0, ctx->stream, a, ps->f); \
+            else hipLaunchKernelGGL((k_linearize_finalize<K, 0, 1>), grid, block, 0, ctx->stream, a, ps->f);    \
+        } else if (halo) hipLaunchKernelGGL((k_linearize_finalize<K, 1, 0>), grid, block, 0, ctx->stream, a, ps->f); \
+        else hipLaunchKernelGGL((k_linearize_finalize<K, 0, 0>), grid, block, 0, ctx->stream, a, ps->f);
         if (!ps->fused_fin) {
             pcr_dev_launch_linearize(ps->kind, halo, grid, ctx->stream, a);
         } else switch (ps->kind) {
@@ -758,6 +775,7 @@ pcr_status pcr_run_align(pcr_target *t, pcr_scan *s, int kind, const double T_in
     // all-reduces move stale sums): no host synchronisation between iterations, at most AHEAD dead all-reduces.
     const int AHEAD = 2;
     int enq = 0;
+    ps.gn_inline = ps.one_kernel && ps.fused_fin && !use_comm;
     auto enqueue_iteration = [&]() -> pcr_status {
         retire_completed(ctx);
         PCR_TRY(pass_enqueue(&ps));
@@ -768,7 +786,7 @@ pcr_status pcr_run_align(pcr_target *t, pcr_scan *s, int kind, const double T_in
             pcr_prof_end(ctx, &ev);
             if (cs != PCR_OK) return cs;
         }
-        hipLaunchKernelGGL(k_gn_update, dim3(1), dim3(64), 0, ctx->stream, f);
+        if (!ps.gn_inline) hipLaunchKernelGGL(k_gn_update, dim3(1), dim3(64), 0, ctx->stream, f);
         HIP_TRY(hipGetLastError());
         ++enq;
         return PCR_OK;

@@ -624,7 +624,8 @@ __device__ __forceinline__ void finalize_emit(const FinArgs &f, const double *to
 // takes a group's last ticket folds the group's partials into row nblocks+g; the group leader that takes the
 // last of the 8 second-level tickets folds those rows and emits.  8 x (nblocks/8) + 8 serialised atomics
 // instead of nblocks.
-__device__ __forceinline__ void ticket_fold_emit(double *acc, const LinArgs &a, const FinArgs &f) {
+// (returns true in the ONE block that folded the last contribution and emitted the result)
+__device__ __forceinline__ bool ticket_fold_emit(double *acc, const LinArgs &a, const FinArgs &f) {
     block_store_partials<true>(acc, a.partials);
 
     __shared__ int role;
@@ -646,7 +647,7 @@ __device__ __forceinline__ void ticket_fold_emit(double *acc, const LinArgs &a, 
         role = t == (uint32_t)(per - 1);
     }
     __syncthreads();
-    if (!role) return;
+    if (!role) return false;
 
     // ---- group leader: rows g + ng i, i = 0 .. per-1, in a fixed order; 16 loads in flight per thread
     const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
@@ -677,7 +678,7 @@ __device__ __forceinline__ void ticket_fold_emit(double *acc, const LinArgs &a, 
         role = t2 == 7u;
     }
     __syncthreads();
-    if (!role) return;
+    if (!role) return false;
 
     // ---- the last group leader: the 8 group rows, in order
     if (threadIdx.x == 0) __hip_atomic_store(ctr2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -690,6 +691,7 @@ __device__ __forceinline__ void ticket_fold_emit(double *acc, const LinArgs &a, 
     }
     __syncthreads();
     finalize_emit(f, tot);
+    return true;
 }
 
 // ---- developer / A-B kernels (kernels_dev.hip): unfused folds, the wave-cooperative search, work counters ----

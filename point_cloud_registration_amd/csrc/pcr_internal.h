@@ -292,6 +292,7 @@ pcr_status pcr_run_align(pcr_target *t, pcr_scan *s, int kind, const double T_in
                          double max_dist, unsigned flags, double T_out[16], int *iterations, double *trace_or_null);
 pcr_status pcr_run_nn(pcr_target *t, const float *d_q, int64_t m, double r_max, void *d_dist, int64_t *d_idx, int f64);
 pcr_status pcr_ensure_scratch(pcr_context *ctx, int64_t n_points);
+bool pcr_pass_is_fused(const pcr_context *ctx, const pcr_scan *s);      // this scan runs the one-kernel (small-scan) form of a pass
 
 // ---- roctx ranges around the hot-path launches (PCR_ROCTX=1; libroctx64 bound with dlopen, so the
 // library loads without it).  Shows up in rocprofv3 --marker-trace / the tool's timeline.

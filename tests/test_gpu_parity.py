@@ -224,6 +224,8 @@ def test_align_matches_reference(capi, g2, name, loop, pipeline):
     kw = {"native_loop": loop != "python"}
     if loop == "hostloop":
         kw["compat_flags"] = capi.FLAG_ICP_RR_QUIRK | capi.FLAG_HOST_LOOP
+    if loop == "device":
+        kw["compat_flags"] = capi.FLAG_ICP_RR_QUIRK | capi.FLAG_DEVICE_LOOP     # (small scans default to the host-driven form)
     obj = _classes(g2, **kw)[name]
     with pytest.raises(ValueError):
         obj.align(g2["source"])                           # target not set (registration.py:80-81)
@@ -255,7 +257,8 @@ def test_align_loop_edge_cases(capi, orc, ctx, g2):
     for name in NAMES:
         kind = kind_of(capi, name)
         for max_iter, tol in ((0, 1e-3), (1, 1e-3), (2, 1e-3), (3, 1e9), (30, 1e-3)):
-            Td, itd, trd = capi.align(gt[name], scan, kind, T0, max_iter, tol, md, want_trace=True)
+            Td, itd, trd = capi.align(gt[name], scan, kind, T0, max_iter, tol, md,
+                                      capi.FLAG_ICP_RR_QUIRK | capi.FLAG_DEVICE_LOOP, want_trace=True)
             Th, ith, trh = capi.align(gt[name], scan, kind, T0, max_iter, tol, md,
                                       capi.FLAG_ICP_RR_QUIRK | capi.FLAG_HOST_LOOP, want_trace=True)
             assert itd == ith and np.array_equal(Td, Th) and np.array_equal(trd, trh), (name, max_iter, tol)

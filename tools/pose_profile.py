@@ -84,7 +84,7 @@ for mode in [int(m) for m in a.modes.split(",")]:
         _capi.linearize(tgt, sc, kind, traj[k % len(traj)], 2.0)
     print(f"  mode {mode} walk wall {((time.perf_counter() - t0) / n) * 1e6:.1f} us/pass", flush=True)
     # (4) whole align(): device-resident loop vs host-driven loop (scan resident)
-    for name, fl in (("device", _capi.FLAG_ICP_RR_QUIRK), ("host", _capi.FLAG_ICP_RR_QUIRK | _capi.FLAG_HOST_LOOP)):
+    for name, fl in (("device", _capi.FLAG_ICP_RR_QUIRK | _capi.FLAG_DEVICE_LOOP), ("host", _capi.FLAG_ICP_RR_QUIRK | _capi.FLAG_HOST_LOOP), ("auto", _capi.FLAG_ICP_RR_QUIRK)):
         ts = []
         for r in range(a.align_reps):
             t0 = time.perf_counter()

@@ -36,7 +36,7 @@ while time.time() - t0 < seconds:
                 passes += 1
         if passes % 50 == 0 and n > 100:        # device-resident loop == host-driven loop, bit for bit
             try:
-                Td, itd = _capi.align(tgt, sc, kind, T, 10, 1e-3, 2.0)
+                Td, itd = _capi.align(tgt, sc, kind, T, 10, 1e-3, 2.0, _capi.FLAG_ICP_RR_QUIRK | _capi.FLAG_DEVICE_LOOP)
                 Th, ith = _capi.align(tgt, sc, kind, T, 10, 1e-3, 2.0, _capi.FLAG_ICP_RR_QUIRK | _capi.FLAG_HOST_LOOP)
             except np.linalg.LinAlgError:
                 Th, ith = None, None

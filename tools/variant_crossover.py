@@ -13,7 +13,7 @@ for kind_name, kind in (("plane", _capi.PLANE), ("icp", _capi.ICP)):
     tgt = _capi.Target.points(ctx, target)
     if kind == _capi.PLANE:
         tgt.estimate_normals(15, want=False)
-    for n in (50_000, 100_000, 200_000, 300_000, 450_000, 700_000, 1_060_000):
+    for n in (100_000, 200_000, 262_000, 300_000, 350_000, 400_000, 450_000, 600_000):
         scan, _ = perturbed_scan(target, n if n < 1_060_000 else None, seed=2)
         sc = _capi.Scan(ctx, scan)
         ctx.set_variant(1)
