@@ -591,7 +591,7 @@ static pcr_status pass_enqueue(Pass *ps) {
                 pcr_dev_launch_coop(nn_grid, ctx->stream, a);
             } else if (!vox) {
                 launch_nn_scan<0>(mode, ps->t->cs_h != nullptr, ps->a.sched_local, nn_grid, ctx->stream, a);
-            } else if (ps->t->gd.rowocc != nullptr && a.md_d / ps->t->gd.h + 2.0 >= 5.0) {
+            } else if (ps->t->gd.rowocc != nullptr && (ctx->vox_occ >= 0 ? ctx->vox_occ != 0 : a.md_d / ps->t->gd.h + 2.0 >= 5.0)) {
                 launch_nn_scan<2>(mode, false, ps->a.sched_local, nn_grid, ctx->stream, a);
             } else {
                 launch_nn_scan<1>(mode, false, ps->a.sched_local, nn_grid, ctx->stream, a);

@@ -190,6 +190,8 @@ struct pcr_context {
     int nn_mode = 0;             // 0 per-lane search; 2 wave-cooperative (developer builds)
     // certified reuse of the previous pass' matches (see kernels.hip: choose_nn_mode)
     double local_frac = 0.35;    // block-local tile hand-out when the scan moved less than this x cell size (PCR_LOCAL_FRAC)
+    double voxel_cell_mult = 2.0; // PCR_VOXEL_CELL_MULT: centroid grid cell edge in voxels
+    int vox_occ = -1;            // PCR_VOX_OCC (developer): force the centroid search's row-bitmap variant on / off; -1 = by gate / cell ratio
     int tile_local = -1;         // PCR_TILE_LOCAL (developer): force the hand-out policy of k_nn_scan; -1 = automatic
     int reuse = 1;               // 0 off, 1 automatic, 2 forced (track + list whenever the state allows: tests)
     double reuse_tau = 0.0125;   // try it when the scan's typical motion since the last pass is below tau x cell size (a quarter of mu)
