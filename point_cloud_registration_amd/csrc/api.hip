@@ -74,6 +74,33 @@ void pcr_cache_clear(pcr_context *ctx) {
     ctx->cache_bytes = 0;
 }
 
+hipError_t pcr_scan_alloc(pcr_scan *s, void **p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    size_t cap = 0;
+    *p = s->ctx ? pcr_cache_get(s->ctx, bytes, &cap) : nullptr;
+    if (!*p) {
+        cap = (bytes + 4095) & ~(size_t)4095;
+        const hipError_t e = pcr_malloc_retry(p, cap);
+        if (e != hipSuccess) { *p = nullptr; return e; }
+    }
+    s->blocks.push_back({*p, cap});
+    return hipSuccess;
+}
+
+void pcr_scan_free(pcr_scan *s, void *p) {
+    if (!p) return;
+    for (size_t i = 0; i < s->blocks.size(); ++i) {
+        if (s->blocks[i].first != p) continue;
+        // the context's work is ordered on its one stream: a later user of the block queues behind this scan's kernels
+        if (s->ctx) pcr_cache_put(s->ctx, p, s->blocks[i].second);
+        else (void)hipFree(p);
+        s->blocks[i] = s->blocks.back();
+        s->blocks.pop_back();
+        return;
+    }
+    (void)hipFree(p);
+}
+
 hipError_t pcr_malloc_retry(void **p, size_t bytes) {
     hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess && pcr_tls_ctx && !pcr_tls_ctx->cache.empty()) {
@@ -537,14 +564,10 @@ extern "C" pcr_status pcr_scan_size(pcr_scan *s, int64_t *n) {
 
 extern "C" pcr_status pcr_scan_destroy(pcr_scan *s) {
     if (!s) return PCR_OK;
-    if (s->ctx) { (void)hipSetDevice(s->ctx->device); (void)hipStreamSynchronize(s->ctx->stream); }
-    if (s->x) (void)hipFree(s->x);
-    if (s->y) (void)hipFree(s->y);
-    if (s->z) (void)hipFree(s->z);
-    if (s->nn_j) (void)hipFree(s->nn_j);
-    if (s->lb2) (void)hipFree(s->lb2);
-    if (s->umask) (void)hipFree(s->umask);
-    if (s->ucnt) (void)hipFree(s->ucnt);
+    if (s->ctx) (void)hipSetDevice(s->ctx->device);
+    // no stream synchronisation and no hipFree: the blocks go back to the context's cache, whose next user runs on
+    // the same stream behind whatever of this scan is still queued (e.g. the no-op tail of a device-resident loop)
+    while (!s->blocks.empty()) pcr_scan_free(s, s->blocks.back().first);
     delete s;
     return PCR_OK;
 }

@@ -648,7 +648,8 @@ pcr_status pcr_sort_scan(pcr_context *ctx, const float *d_xyz, int64_t n, unsign
     PCR_REQUIRE(n < ((int64_t)1 << 31), "at most 2^31-1 points per scan shard");
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t nn = (size_t)(n > 0 ? n : 1);
-    HIP_TRY(pcr_malloc_retry((void **)&s->x, 4 * nn)); HIP_TRY(pcr_malloc_retry((void **)&s->y, 4 * nn)); HIP_TRY(pcr_malloc_retry((void **)&s->z, 4 * nn));
+    s->ctx = ctx;
+    HIP_TRY(pcr_scan_alloc(s, (void **)&s->x, 4 * nn)); HIP_TRY(pcr_scan_alloc(s, (void **)&s->y, 4 * nn)); HIP_TRY(pcr_scan_alloc(s, (void **)&s->z, 4 * nn));
     s->n = n;
     if (n == 0) return PCR_OK;
     const unsigned nb = (unsigned)((n + 255) / 256);

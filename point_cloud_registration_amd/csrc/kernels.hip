@@ -418,7 +418,7 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
     // and runs fused (tools/variant_crossover.py: 100 k points 74 vs 80 us per pass, 300 k 97 vs 92, 1.06 M 190 vs 151)
     const bool one_kernel = pcr_pass_is_fused(ctx, s);
     if (!one_kernel && !s->nn_j) {
-        HIP_TRY(pcr_malloc_retry((void **)&s->nn_j, sizeof(uint32_t) * (size_t)(s->n > 0 ? s->n : 1)));
+        HIP_TRY(pcr_scan_alloc(s, (void **)&s->nn_j, sizeof(uint32_t) * (size_t)(s->n > 0 ? s->n : 1)));
         s->nn_serial = 0;
     }
     const int nblocks_split = [&] {
@@ -431,15 +431,15 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
     if (!one_kernel && ctx->reuse != 0 && ctx->nn_mode == 0 && s->n > 0) {
         if (!s->lb2) {
             const size_t words = (((size_t)s->n + 63) / 64 + 31) & ~(size_t)15;     // whole 16-word chunks + slack
-            HIP_TRY(pcr_malloc_retry((void **)&s->lb2, sizeof(float) * (size_t)s->n));
-            HIP_TRY(pcr_malloc_retry((void **)&s->umask, sizeof(unsigned long long) * words));
+            HIP_TRY(pcr_scan_alloc(s, (void **)&s->lb2, sizeof(float) * (size_t)s->n));
+            HIP_TRY(pcr_scan_alloc(s, (void **)&s->umask, sizeof(unsigned long long) * words));
             HIP_TRY(hipMemsetAsync(s->umask, 0, sizeof(unsigned long long) * words, ctx->stream));
             s->track_valid = false;
         }
         if (s->ucnt_cap < nblocks_split) {
-            if (s->ucnt) HIP_TRY(hipFree(s->ucnt));
+            pcr_scan_free(s, s->ucnt);
             s->ucnt = nullptr; s->ucnt_cap = 0;
-            HIP_TRY(pcr_malloc_retry((void **)&s->ucnt, sizeof(uint32_t) * (size_t)nblocks_split));
+            HIP_TRY(pcr_scan_alloc(s, (void **)&s->ucnt, sizeof(uint32_t) * (size_t)nblocks_split));
             s->ucnt_cap = nblocks_split;
         }
         ps->reuse_ready = true;

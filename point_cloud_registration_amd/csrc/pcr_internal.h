@@ -271,7 +271,13 @@ struct pcr_scan {
     int last_mode = 0;
     int64_t last_marked = 0;               // (-1: a LIST pass whose count was not read back)
     double last_motion = -1;
+    // every device block above, with its capacity: pcr_scan_destroy hands them back to the context's block cache
+    // (seven hipFree calls used to be half of what `align(host array)` spends on upload + release, tools/align_seam_probe.py)
+    std::vector<std::pair<void *, size_t>> blocks;
 };
+// device memory owned by a scan: from the context's block cache when a block fits, else hipMalloc
+hipError_t pcr_scan_alloc(pcr_scan *s, void **p, size_t bytes);
+void pcr_scan_free(pcr_scan *s, void *p);      // one block back to the cache (nullptr: no-op)
 
 // what a pass does with the matches of the previous one
 #define PCR_NN_FULL 0     // plain exact search of every point
