@@ -38,12 +38,13 @@ extern "C" pcr_status pcr_device_count(int *count) {
 thread_local pcr_context *pcr_tls_ctx = nullptr;
 static const size_t PCR_CACHE_LIMIT = (size_t)1 << 30;        // at most 1 GiB of idle blocks per context
 
-void *pcr_cache_get(pcr_context *ctx, size_t bytes, size_t *cap_out) {
-    // smallest cached block that fits and is not wastefully large (<= 1.5x + 1 MiB)
+void *pcr_cache_get(pcr_context *ctx, size_t bytes, size_t *cap_out, bool tight) {
+    // smallest cached block that fits and is not wastefully large (<= 1.5x + 1 MiB; tight, for blocks that stay: 1.125x + 256 KiB)
+    const size_t most = tight ? bytes + bytes / 8 + ((size_t)256 << 10) : bytes + bytes / 2 + ((size_t)1 << 20);
     int best = -1;
     for (int i = 0; i < (int)ctx->cache.size(); ++i) {
         const size_t c = ctx->cache[i].first;
-        if (c >= bytes && c <= bytes + bytes / 2 + ((size_t)1 << 20) && (best < 0 || c < ctx->cache[best].first)) best = i;
+        if (c >= bytes && c <= most && (best < 0 || c < ctx->cache[best].first)) best = i;
     }
     if (best < 0) return nullptr;
     void *p = ctx->cache[best].second;
@@ -72,6 +73,35 @@ void pcr_cache_clear(pcr_context *ctx) {
     for (auto &e : ctx->cache) (void)hipFree(e.second);
     ctx->cache.clear();
     ctx->cache_bytes = 0;
+}
+
+hipError_t pcr_persist_alloc(void **p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    pcr_context *ctx = pcr_tls_ctx;
+    if (!ctx) return hipMalloc(p, bytes);
+    size_t cap = 0;
+    *p = pcr_cache_get(ctx, bytes, &cap, true);
+    if (!*p) {
+        cap = (bytes + 4095) & ~(size_t)4095;
+        const hipError_t e = pcr_malloc_retry(p, cap);
+        if (e != hipSuccess) { *p = nullptr; return e; }
+    }
+    ctx->owned[*p] = cap;
+    return hipSuccess;
+}
+
+void pcr_persist_free(pcr_context *ctx, void *p) {
+    if (!p) return;
+    if (ctx) {
+        auto it = ctx->owned.find(p);
+        if (it != ctx->owned.end()) {
+            const size_t cap = it->second;
+            ctx->owned.erase(it);
+            pcr_cache_put(ctx, p, cap);      // reused only by this context's stream: ordered behind the old owner's kernels
+            return;
+        }
+    }
+    (void)hipFree(p);
 }
 
 hipError_t pcr_scan_alloc(pcr_scan *s, void **p, size_t bytes) {
@@ -351,7 +381,8 @@ static void target_free(pcr_target *t) {
     if (!t) return;
     void *ptrs[] = {t->cell_start, t->cell_seed, t->rowocc, t->cs_h, t->pts_h, t->j_h, t->pts, t->pn, t->means, t->vnorm, t->vicov,
                     t->st_mean, t->st_cov, t->st_norm, t->st_icov, t->st_counts, t->st_keys};
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (t->ctx) (void)hipSetDevice(t->ctx->device);
+    for (void *p : ptrs) pcr_persist_free(t->ctx, p);
     delete t;
 }
 
@@ -362,7 +393,7 @@ static pcr_status points_create_common(pcr_context *ctx, const float *d_xyz, int
     t->ctx = ctx; t->is_voxel = 0; t->n = n; t->serial = ctx->next_serial++;
     pcr_status s = pcr_build_point_grid(ctx, d_xyz, n, cell_hint, t);
     if (s == PCR_OK && d_normals) {
-        hipError_t e = pcr_malloc_retry((void **)&t->pn, sizeof(PtN) * (size_t)(n ? n : 1));
+        hipError_t e = pcr_persist_alloc((void **)&t->pn, sizeof(PtN) * (size_t)(n ? n : 1));
         if (e != hipSuccess) { pcr_set_error("hipMalloc normals: %s", hipGetErrorString(e)); s = PCR_ERR_HIP; }
         else s = pcr_permute_normals(ctx, d_normals, n, t->pts, t->pn);
         if (s == PCR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s = PCR_ERR_HIP;
@@ -402,7 +433,7 @@ extern "C" pcr_status pcr_target_set_normals(pcr_target *t, const float *normals
     CtxScope scope(ctx);
     DevBuf<float> d_nrm;
     PCR_TRY(upload<float>(ctx, normals, (size_t)t->n * 3, &d_nrm));
-    if (!t->pn) HIP_TRY(pcr_malloc_retry((void **)&t->pn, sizeof(PtN) * (size_t)(t->n ? t->n : 1)));
+    if (!t->pn) HIP_TRY(pcr_persist_alloc((void **)&t->pn, sizeof(PtN) * (size_t)(t->n ? t->n : 1)));
     PCR_TRY(pcr_permute_normals(ctx, d_nrm.p, t->n, t->pts, t->pn));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PCR_OK;
@@ -444,12 +475,12 @@ pcr_status pcr_voxel_target_finish(pcr_context *ctx, pcr_target *t, double voxel
     PCR_TRY(pcr_build_centroid_grid(ctx, t->st_mean, t->n, voxel_size * ctx->voxel_cell_mult, t));
     const size_t nn = (size_t)(t->n ? t->n : 1);
     if (t->st_norm) {
-        HIP_TRY(pcr_malloc_retry((void **)&t->vnorm, sizeof(double) * 3 * nn));
+        HIP_TRY(pcr_persist_alloc((void **)&t->vnorm, sizeof(double) * 3 * nn));
         const int cols[3] = {0, 1, 2};
         PCR_TRY(pcr_permute_rows_f64(ctx, t->st_norm, t->n, 3, cols, 3, t->means, t->vnorm));
     }
     if (t->st_icov) {
-        HIP_TRY(pcr_malloc_retry((void **)&t->vicov, sizeof(double) * 6 * nn));
+        HIP_TRY(pcr_persist_alloc((void **)&t->vicov, sizeof(double) * 6 * nn));
         const int cols[6] = {0, 1, 2, 4, 5, 8};
         PCR_TRY(pcr_permute_rows_f64(ctx, t->st_icov, t->n, 9, cols, 6, t->means, t->vicov));
     }

@@ -214,7 +214,7 @@ extern "C" pcr_status pcr_target_estimate_normals(pcr_target *t, int k, int comp
     PCR_TRY(check_k(k));
     pcr_context *ctx = t->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
-    if (!t->pn) HIP_TRY(pcr_malloc_retry((void **)&t->pn, sizeof(PtN) * (size_t)(t->n ? t->n : 1)));
+    if (!t->pn) HIP_TRY(pcr_persist_alloc((void **)&t->pn, sizeof(PtN) * (size_t)(t->n ? t->n : 1)));
     if (t->n > 0) {
         const size_t smem = 3 * sizeof(float) * (size_t)k * KNN_BLOCK;
         hipLaunchKernelGGL(k_knn_normals, dim3((unsigned)((t->n + KNN_BLOCK - 1) / KNN_BLOCK)), dim3(KNN_BLOCK), smem,

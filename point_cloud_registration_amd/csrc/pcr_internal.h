@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -100,12 +101,17 @@ struct PoseDev {
 // on its ONE stream, so reusing a block is ordered behind its previous user.  Blocks are whole hipMalloc
 // allocations: release() can still hand one over to a persistent owner that hipFree()s it later.
 struct pcr_context;
-void *pcr_cache_get(pcr_context *ctx, size_t bytes, size_t *cap_out);     // nullptr: nothing suitable cached
+void *pcr_cache_get(pcr_context *ctx, size_t bytes, size_t *cap_out, bool tight = false);     // nullptr: nothing suitable cached
 void pcr_cache_put(pcr_context *ctx, void *p, size_t cap);
 void pcr_cache_clear(pcr_context *ctx);
 extern thread_local pcr_context *pcr_tls_ctx;
 // hipMalloc; on failure the current context's idle blocks (up to 1 GiB) are released and the call is retried once
 hipError_t pcr_malloc_retry(void **p, size_t bytes);
+// Persistent blocks (what a target keeps): taken from the current context's cache when a block fits TIGHTLY (at most
+// 1/8 + 256 KiB larger), registered with their capacity in that context (pcr_context::owned), and handed back to its cache
+// by pcr_persist_free -- set_target over an old target used to pay ~17 hipFree + ~17 hipMalloc calls (~60 us each).
+hipError_t pcr_persist_alloc(void **p, size_t bytes);
+void pcr_persist_free(pcr_context *ctx, void *p);          // unregistered pointers are hipFree()d; nullptr: no-op
 struct CtxScope {
     pcr_context *prev;
     explicit CtxScope(pcr_context *ctx) : prev(pcr_tls_ctx) { pcr_tls_ctx = ctx; }
@@ -119,17 +125,20 @@ struct DevBuf {
     T *p = nullptr;
     size_t cap = 0;                 // bytes of the underlying block
     pcr_context *owner = nullptr;   // context whose cache the block goes back to (nullptr: plain hipFree)
+    bool persist = false;           // block registered in owner->owned (alloc_exact)
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { reset(); }
     hipError_t alloc(size_t count) { return alloc_bytes(sizeof(T) * (count ? count : 1)); }
-    // exactly-sized, never from the cache: for buffers that will be release()d to a persistent owner
+    // tightly sized, registered as a persistent block: for buffers that will be release()d to a persistent owner,
+    // which frees them with pcr_persist_free
     hipError_t alloc_exact(size_t count) {
         reset();
-        owner = nullptr;
+        owner = pcr_tls_ctx;
+        persist = true;
         cap = sizeof(T) * (count ? count : 1);
-        const hipError_t e = pcr_malloc_retry((void **)&p, cap);
+        const hipError_t e = pcr_persist_alloc((void **)&p, cap);
         if (e != hipSuccess) { p = nullptr; cap = 0; }
         return e;
     }
@@ -137,6 +146,7 @@ struct DevBuf {
         reset();
         if (bytes == 0) bytes = 16;
         owner = pcr_tls_ctx;
+        persist = false;
         if (owner) {
             p = (T *)pcr_cache_get(owner, bytes, &cap);
             if (p) return hipSuccess;
@@ -149,7 +159,8 @@ struct DevBuf {
     }
     void reset() {
         if (p) {
-            if (owner) pcr_cache_put(owner, p, cap);
+            if (persist) pcr_persist_free(owner, p);
+            else if (owner) pcr_cache_put(owner, p, cap);
             else (void)hipFree(p);
         }
         p = nullptr; cap = 0;
@@ -215,6 +226,7 @@ struct pcr_context {
     // cache of free device blocks (temporaries of the build paths): (capacity, pointer), total bytes
     std::vector<std::pair<size_t, void *>> cache;
     size_t cache_bytes = 0;
+    std::unordered_map<void *, size_t> owned;    // persistent blocks handed out by pcr_persist_alloc: capacity
 };
 
 struct pcr_target {

@@ -160,9 +160,9 @@ static pcr_status voxel_build(pcr_context *ctx, const T *d_xyz, int64_t n, doubl
     }
     {
         const size_t kk = (size_t)(nk > 0 ? nk : 1);
-        HIP_TRY(pcr_malloc_retry((void **)&t->st_mean, 8 * 3 * kk)); HIP_TRY(pcr_malloc_retry((void **)&t->st_cov, 8 * 9 * kk));
-        HIP_TRY(pcr_malloc_retry((void **)&t->st_norm, 8 * 3 * kk)); HIP_TRY(pcr_malloc_retry((void **)&t->st_icov, 8 * 9 * kk));
-        HIP_TRY(pcr_malloc_retry((void **)&t->st_counts, 8 * kk)); HIP_TRY(pcr_malloc_retry((void **)&t->st_keys, 8 * kk));
+        HIP_TRY(pcr_persist_alloc((void **)&t->st_mean, 8 * 3 * kk)); HIP_TRY(pcr_persist_alloc((void **)&t->st_cov, 8 * 9 * kk));
+        HIP_TRY(pcr_persist_alloc((void **)&t->st_norm, 8 * 3 * kk)); HIP_TRY(pcr_persist_alloc((void **)&t->st_icov, 8 * 9 * kk));
+        HIP_TRY(pcr_persist_alloc((void **)&t->st_counts, 8 * kk)); HIP_TRY(pcr_persist_alloc((void **)&t->st_keys, 8 * kk));
         if (nu > 0) {
             hipLaunchKernelGGL(k_voxel_stats<T>, dim3((unsigned)((nu + 3) / 4)), dim3(256), 0, ctx->stream, d_xyz, i2.p,
                                ukeys.p, counts.p, seg.p, flags.p, nu, min_points, t->st_mean, t->st_cov, t->st_norm, t->st_icov,

@@ -25,3 +25,6 @@ timeout 1200 python tools/reuse_probe.py --config plane_100m_resampled --reps 3 
 tools/collect_profiles.sh r03_plane_b01 plane_b01
 tools/collect_profiles.sh r03_plane_100m plane_100m
 tools/collect_profiles.sh r03_icp_b01_harness icp_b01_harness
+tools/collect_profiles.sh r03_vplane_10m vplane_10m
+tools/collect_profiles.sh r03_ndt_10m ndt_10m
+timeout 200 python tools/align_seam_probe.py 2>&1 | grep -v '^/opt' | head -8 > $o/r03_seam_align.txt; timeout 200 python tools/set_target_probe.py 2>&1 | grep -v '^/opt' | head -8 >> $o/r03_seam_align.txt; cat $o/r03_seam_align.txt
