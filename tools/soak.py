@@ -15,7 +15,20 @@ tp = _capi.Target.points(ctx, target); tp.estimate_normals(10, want=False)
 tv = _capi.Target.voxels(ctx, target, 1.0, 10)
 full, _ = perturbed_scan(target, None, seed=4)
 t0 = time.time(); passes = 0; scans = 0
+rebuilds = 0
 while time.time() - t0 < seconds:
+    if scans % 8 == 7:                          # targets come and go too: their blocks are recycled through the context's cache
+        m = int(rng.choice([50_000, 200_000, 400_000, int(rng.integers(20_000, 400_000))]))
+        sub = target[np.sort(rng.permutation(len(target))[:m])].copy()
+        tp.close(); tv.close()
+        tp = _capi.Target.points(ctx, sub); tp.estimate_normals(10, want=False)
+        tv = _capi.Target.voxels(ctx, sub, 1.0, 10)
+        q = full[rng.integers(0, len(full), 256)]
+        d, i = tp.nn_query(q)
+        db = np.sqrt(((q[:, None, :].astype(np.float64) - sub[None, :, :].astype(np.float64)) ** 2).sum(-1).min(1))
+        if not np.allclose(d, db, rtol=1e-5, atol=1e-6):
+            print("TARGET MISMATCH after rebuild", m, np.max(np.abs(d - db))); sys.exit(1)
+        rebuilds += 1
     n = int(rng.choice([1, 7, 63, 64, 65, 500, 2047, 2048, 2049, 30_000, 131_072, 131_073, 250_000, int(rng.integers(1, 400_000))]))
     sc = _capi.Scan(ctx, full[rng.permutation(len(full))[:n]].copy()); scans += 1
     for _ in range(40):
@@ -43,4 +56,4 @@ while time.time() - t0 < seconds:
             if Th is not None and (itd != ith or not np.array_equal(Td, Th)):
                 print("LOOP MISMATCH", n, kind, itd, ith); sys.exit(1)
     sc.close()
-print(f"soak ok: {passes} passes over {scans} scans in {time.time() - t0:.1f} s")
+print(f"soak ok: {passes} passes over {scans} scans, {rebuilds} target rebuilds in {time.time() - t0:.1f} s")
