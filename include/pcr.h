@@ -189,7 +189,8 @@ PCR_API pcr_status pcr_profile_read(pcr_context *ctx, int64_t launches[PCR_K_COU
 PCR_API pcr_status pcr_target_index_info(pcr_target *t, double *cell, int64_t dims[3], int64_t *occupied, int64_t *n);
 /* point targets: margin (metres) and total records of the extended per-cell lists ring 0 searches (a cell's
  * own points plus the neighbours' points within the margin of the shared face; PCR_HALO sets the margin as a
- * fraction of the cell edge, default 0.1, 0 = none)                                                        */
+ * fraction of the cell edge, default 0.1, 0 = none).  Voxel targets: the same of the float32 filter index over
+ * the rounded centroids (both 0: the target has no filter -- coordinates too large -- and searches in float64) */
 PCR_API pcr_status pcr_target_index_halo(pcr_target *t, double *halo, int64_t *records);
 /* work counters of the NN search for one pose (point targets): out[0..3] = rings entered, row
  * segments loaded, rows pruned by arithmetic, candidates tested, summed over queries; out[4..7] = the
@@ -202,7 +203,9 @@ PCR_API pcr_status pcr_nn_counters(pcr_target *t, pcr_scan *s, const double T[16
  * points 49 vs 59 us per pass); either way the last blocks fold the partial sums inside the kernel   */
 PCR_API pcr_status pcr_set_variant(pcr_context *ctx, int variant);
 PCR_API pcr_status pcr_get_variant(pcr_context *ctx, int *variant);
-/* NN search kernel of variant 1: 0 = per-lane ring search (shipped), 2 = wave-cooperative LDS-staged search */
+/* NN search kernel of variant 1: 0 = per-lane ring search (shipped; plain passes over a voxel target run a float32 filter
+ * search over the rounded centroids and check its winner in float64 -- results identical to the float64 search),
+ * 2 = wave-cooperative LDS-staged search, 3 = as 0 with the centroid search in float64 throughout (A/B, tests) */
 PCR_API pcr_status pcr_set_nn_mode(pcr_context *ctx, int mode);
 /* Certified reuse of the previous pass' matches (no reference counterpart: Registration.align,
  * registration.py:89-111, searches afresh every iteration).  When consecutive passes over one scan and target

@@ -172,6 +172,8 @@ extern "C" pcr_status pcr_context_create(int device, pcr_context **out) {
     if (lf && *lf) ctx->local_frac = atof(lf);
     const char *cm = getenv("PCR_VOXEL_CELL_MULT");
     if (cm && atof(cm) > 0) ctx->voxel_cell_mult = atof(cm);
+    const char *vf = getenv("PCR_VOX_FILTER");
+    if (vf && *vf) ctx->vox_filter = atoi(vf) != 0;
     const char *vo = getenv("PCR_VOX_OCC");
     if (vo && *vo) ctx->vox_occ = atoi(vo) != 0;
     const char *tl = getenv("PCR_TILE_LOCAL");
@@ -250,7 +252,7 @@ extern "C" pcr_status pcr_get_pipeline(pcr_context *ctx, int *variant, int *fuse
 
 extern "C" pcr_status pcr_set_nn_mode(pcr_context *ctx, int mode) {
     PCR_REQUIRE(ctx, "ctx is NULL");
-    PCR_REQUIRE(mode == 0 || mode == 2, "nn mode must be 0 or 2");
+    PCR_REQUIRE(mode == 0 || mode == 2 || mode == 3, "nn mode must be 0, 2 or 3");
     ctx->nn_mode = mode;
     return PCR_OK;
 }
@@ -379,6 +381,7 @@ static pcr_status upload(pcr_context *ctx, const T *host, size_t count, DevBuf<T
 
 static void target_free(pcr_target *t) {
     if (!t) return;
+    target_free(t->filter);
     void *ptrs[] = {t->cell_start, t->cell_seed, t->rowocc, t->cs_h, t->pts_h, t->j_h, t->pts, t->pn, t->means, t->vnorm, t->vicov,
                     t->st_mean, t->st_cov, t->st_norm, t->st_icov, t->st_counts, t->st_keys};
     if (t->ctx) (void)hipSetDevice(t->ctx->device);
@@ -473,6 +476,7 @@ pcr_status pcr_voxel_target_finish(pcr_context *ctx, pcr_target *t, double voxel
     // the point grid's automatic cell size aims for too.  Measured (vplane_10m, search us per
     // pose): 1x 940, 1.5x 880, 2x 830, 2.5x 1020, 3x 1150; ndt_10m totals are equal at 1x and 2x.
     PCR_TRY(pcr_build_centroid_grid(ctx, t->st_mean, t->n, voxel_size * ctx->voxel_cell_mult, t));
+    PCR_TRY(pcr_build_centroid_filter(ctx, t));
     const size_t nn = (size_t)(t->n ? t->n : 1);
     if (t->st_norm) {
         HIP_TRY(pcr_persist_alloc((void **)&t->vnorm, sizeof(double) * 3 * nn));
@@ -550,8 +554,9 @@ extern "C" pcr_status pcr_target_index_info(pcr_target *t, double *cell, int64_t
 
 extern "C" pcr_status pcr_target_index_halo(pcr_target *t, double *halo, int64_t *records) {
     PCR_REQUIRE(t, "NULL argument");
-    if (halo) *halo = t->is_voxel ? 0.0 : (double)t->gf.halo;
-    if (records) *records = t->n_h;
+    const pcr_target *p = t->is_voxel ? t->filter : t;      // voxel targets: the float32 filter index of the centroid search
+    if (halo) *halo = p ? (double)p->gf.halo : 0.0;
+    if (records) *records = p ? p->n_h : 0;
     return PCR_OK;
 }
 

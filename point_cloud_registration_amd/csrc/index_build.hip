@@ -545,9 +545,9 @@ pcr_status pcr_count_nonfinite(pcr_context *ctx, const void *d_xyz, int is_f64, 
     return device_bbox<float>(ctx, (const float *)d_xyz, n, lo, hi, count);
 }
 
-pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n, float cell_hint, pcr_target *t) {
+pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n, float cell_hint, pcr_target *t, bool use_env) {
     double h = cell_hint > 0 ? (double)cell_hint : 0.5;
-    const char *env = getenv("PCR_GRID_CELL");
+    const char *env = use_env ? getenv("PCR_GRID_CELL") : nullptr;
     bool auto_h = !(cell_hint > 0);
     if (env && atof(env) > 0) { h = atof(env); auto_h = false; }
     // halo margin as a fraction of the cell edge (PCR_HALO; 0 = no extended lists).  0.1: ~1.7 copies per
@@ -568,6 +568,41 @@ pcr_status pcr_build_centroid_grid(pcr_context *ctx, const double *d_mean, int64
                                              0.0, &cs_h, &pts_h, &j_h, &n_h)));
     const char *oe = getenv("PCR_ROW_OCC");
     if (n > 0 && !(oe && atoi(oe) == 0)) PCR_TRY(make_row_occ<double>(ctx, t->cell_start, &t->gd, &t->rowocc));
+    return PCR_OK;
+}
+
+// ---- float32 filter of a centroid search (pass_device.h: nn_point_filter) ----------------------
+__global__ void __launch_bounds__(256) k_means_to_f32(const PtD *__restrict__ means, int64_t n, float *__restrict__ xyz) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const PtD m = means[j];
+    xyz[3 * j] = (float)m.x; xyz[3 * j + 1] = (float)m.y; xyz[3 * j + 2] = (float)m.z;     // round to nearest
+}
+
+// A point index over the float32-rounded centroids, built from the CELL-SORTED array `means`: the "original index" a
+// float32 search returns is then the index the reduce kernels gather with.  Only when rounding moves a centroid by
+// less than 1 % of a cell (coordinates below ~1e5 m for 1 m cells): beyond that the filter would rarely certify.
+pcr_status pcr_build_centroid_filter(pcr_context *ctx, pcr_target *t) {
+    if (t->n <= 0 || !ctx->vox_filter) return PCR_OK;
+    const Geom<double> &g = t->gd;
+    double maxabs = 0;
+    const double lo[3] = {g.ox, g.oy, g.oz}, ext[3] = {g.nx * g.h, g.ny * g.h, g.nz * g.h};
+    for (int i = 0; i < 3; ++i) {
+        maxabs = fmax(maxabs, fabs(lo[i]));
+        maxabs = fmax(maxabs, fabs(lo[i] + ext[i]));
+    }
+    // half an ulp per coordinate = 2^-24 relative; sqrt(3) for the vector; 1 % on top
+    const double band = 1.7321 * 1.01 * maxabs * 5.9604644775390625e-8 + 1e-30;
+    if (!(band <= 0.01 * g.h)) return PCR_OK;
+    DevBuf<float> xyz;
+    HIP_TRY(xyz.alloc((size_t)t->n * 3));
+    hipLaunchKernelGGL(k_means_to_f32, dim3((unsigned)((t->n + 255) / 256)), dim3(256), 0, ctx->stream, t->means, t->n, xyz.p);
+    HIP_TRY(hipGetLastError());
+    pcr_target *f = new pcr_target();
+    f->ctx = ctx; f->n = t->n;
+    t->filter = f;                                   // (owned by t from here on: freed with it, also on the error path)
+    PCR_TRY(pcr_build_point_grid(ctx, xyz.p, t->n, (float)g.h, f, false));
+    t->filter_band = band;
     return PCR_OK;
 }
 

@@ -189,6 +189,36 @@ __global__ void __launch_bounds__(256, VOXEL == 2 ? PCR_VOX_WAVES : 5) k_nn_scan
     }
 }
 
+// Plain pass over a voxel target that has a float32 filter index (pass_device.h: nn_point_filter)
+template <int HALO, int LOCAL>
+__global__ void __launch_bounds__(256, 5) k_nn_filter(const LinArgs a) {
+    PoseK P;
+    if (!load_pose<false>(a, P)) return;
+    auto body = [&](int64_t first, int64_t end) {
+        const int64_t i = first + (threadIdx.x & 63);
+        if (i < end) nn_point_filter<HALO>(a, P, i);
+    };
+    nn_tile_loop<LOCAL, 64>(a, body);
+}
+// ... and the float64 search of what it could not certify; returns at once when no lane of this pass asked
+__global__ void __launch_bounds__(256) k_nn_fix(const LinArgs a) {
+    PoseK P;
+    if (!load_pose<false>(a, P)) return;
+    if (__builtin_amdgcn_readfirstlane(*(volatile const uint32_t *)a.pending) != a.stamp) return;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256)
+        if (a.nn_j[i] == PCR_PENDING) nn_point_fix(a, P, i);
+}
+static void launch_nn_filter(bool halo, int local, dim3 grid, hipStream_t st, const LinArgs &a) {
+    const dim3 block(256);
+#define PCR_NF_CASE(H, L) hipLaunchKernelGGL((k_nn_filter<H, L>), grid, block, 0, st, a)
+    // (local == 2, "decided on the device from the size of the step", is not instantiated here: both tile loops in one
+    // kernel around the tracking search spill 736 bytes per lane; the device-resident loop keeps the global counters)
+    if (halo) { if (local == 1) PCR_NF_CASE(1, 1); else PCR_NF_CASE(1, 0); }
+    else { if (local == 1) PCR_NF_CASE(0, 1); else PCR_NF_CASE(0, 0); }
+#undef PCR_NF_CASE
+    hipLaunchKernelGGL(k_nn_fix, grid, block, 0, st, a);
+}
+
 // host-side choice of the instantiation
 // (local: 0 global counters, 1 block-local, 2 decided on the device -- plain searches of the device-resident loop only)
 template <int VOXEL, int MODE>
@@ -348,14 +378,16 @@ pcr_status pcr_ensure_scratch(pcr_context *ctx, int64_t n_points) {
         memset(ctx->h_out, 0, sizeof(double) * 64);
         HIP_TRY(hipHostGetDevicePointer((void **)&ctx->h_out_dev, ctx->h_out, 0));
         // 8 + 1 tickets (64 B apart), then the tile counters
-        const size_t ctr_words = 9 * 16 + (size_t)PCR_TILE_CTRS * PCR_TILE_STRIDE;
+        // ... then the word of k_nn_fix (the stamp of the last filter pass that left work for it)
+        const size_t ctr_words = 9 * 16 + (size_t)PCR_TILE_CTRS * PCR_TILE_STRIDE + 16;
         HIP_TRY(pcr_malloc_retry((void **)&ctx->d_tile_ctr, sizeof(uint32_t) * ctr_words));
         HIP_TRY(hipMemsetAsync(ctx->d_tile_ctr, 0, sizeof(uint32_t) * ctr_words, ctx->stream));
-        for (int v = 0; v < 3; ++v) {
+        for (int v = 0; v < 4; ++v) {
             int nb = 0;
             if (v == 2) { ctx->nn_blocks_per_cu[v] = pcr_dev_coop_blocks_per_cu(); continue; }
             hipError_t e = v == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<0, 1, 0, 0>, 256, 0)
-                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<1, 0, 0, 0>, 256, 0);
+                         : v == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<1, 0, 0, 0>, 256, 0)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_filter<1, 0>, 256, 0);
             ctx->nn_blocks_per_cu[v] = (e == hipSuccess && nb > 0) ? nb : 4;
         }
     }
@@ -396,6 +428,7 @@ bool pcr_pass_is_fused(const pcr_context *ctx, const pcr_scan *s) {
     return ctx->variant == 0;
 }
 
+static void set_filter_bound(LinArgs &a, double bound);
 static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, double max_dist, unsigned flags) {
     pcr_context *ctx = t->ctx;
     PCR_REQUIRE(s->ctx == ctx, "scan and target belong to different contexts");
@@ -428,7 +461,7 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
         return nb < 8 ? 8 : nb;
     }();
     ps->reuse_ready = false;
-    if (!one_kernel && ctx->reuse != 0 && ctx->nn_mode == 0 && s->n > 0) {
+    if (!one_kernel && ctx->reuse != 0 && (ctx->nn_mode == 0 || ctx->nn_mode == 3) && s->n > 0) {
         if (!s->lb2) {
             const size_t words = (((size_t)s->n + 63) / 64 + 31) & ~(size_t)15;     // whole 16-word chunks + slack
             HIP_TRY(pcr_scan_alloc(s, (void **)&s->lb2, sizeof(float) * (size_t)s->n));
@@ -451,13 +484,19 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
     a.gf = t->gf; a.pts = t->pts; a.pn = t->pn;
     a.gd = t->gd; a.means = t->means; a.vnorm = t->vnorm; a.vicov = t->vicov;
     a.cell_start = t->cell_start;
+    if (t->is_voxel && t->filter && ctx->vox_filter && ctx->nn_mode != 3) {
+        a.gf = t->filter->gf; a.pts = t->filter->pts; a.cs_f = t->filter->cell_start;
+        a.band_f = (float)(t->filter_band * 1.000001);
+    }
     a.md_f = (float)max_dist; a.md_d = max_dist;
     const double bound = max_dist * (1.0 + 1e-6);
     a.bound2_f = (float)(bound * bound); a.bound2_d = bound * bound;
+    set_filter_bound(a, bound);
     a.flags = flags;
     a.nblocks = choose_blocks(ctx, s->n);
     a.partials = ctx->d_partials;
     a.nn_j = s->nn_j; a.tile_ctr = ctx->d_tile_ctr + 9 * 16;
+    a.pending = ctx->d_tile_ctr + 9 * 16 + (size_t)PCR_TILE_CTRS * PCR_TILE_STRIDE;
     a.lb2 = s->lb2; a.umask = s->umask; a.ucnt = s->ucnt;
     a.mu_f = (float)(ctx->reuse_mu * (t->is_voxel ? t->gd.h : (double)t->gf.h));
     if (!one_kernel && a.nblocks > ctx->num_cu * 4) a.nblocks = ctx->num_cu * 4;   // k_reduce streams: 4 blocks/CU
@@ -495,6 +534,14 @@ static void pass_set_host_pose(Pass *ps, const double T[16]) {
     }
 }
 
+// bound and margin of the float32 filter search (nn_point_filter) that go with a float64 search bound
+static void set_filter_bound(LinArgs &a, double bound) {
+    if (a.band_f <= 0.f) return;
+    const double bf = (bound + (double)a.band_f) * 1.00002;
+    a.bound2_ff = (float)(bf * bf * 1.000001);
+    a.mu_ff = (float)(2.0 * (double)a.band_f + 3e-5 * bf);
+}
+
 // What the search of a pass does (gn_math.h: gn_choose_nn_mode) and the search bound that goes with it: a tracking
 // search looks 5 % beyond the gate, so that a point with nothing in reach can be certified "still nothing" later.
 static void pass_set_mode(Pass *ps, int mode) {
@@ -503,6 +550,7 @@ static void pass_set_mode(Pass *ps, int mode) {
     const double md = ps->a.md_d;
     const double bound = mode == PCR_NN_FULL ? md * (1.0 + 1e-6) : md * 1.05;
     ps->a.bound2_f = (float)(bound * bound); ps->a.bound2_d = bound * bound;
+    set_filter_bound(ps->a, bound);
 }
 
 static int host_choose_mode(const Pass *ps, const double T[16], double *motion_out) {
@@ -566,7 +614,8 @@ static pcr_status pass_enqueue(Pass *ps) {
         pcr_prof_begin(ctx, PCR_K_NN, &ev);
         {   // exactly one resident generation of waves; they share the tiles dynamically
             RoctxRange range("pcr:nn_search");
-            int64_t nb = (int64_t)ctx->num_cu * ctx->nn_blocks_per_cu[vox ? 1 : (ctx->nn_mode == 2 ? 2 : 0)];
+            const bool filter = vox && mode == PCR_NN_FULL && a.band_f > 0.f;
+            int64_t nb = (int64_t)ctx->num_cu * ctx->nn_blocks_per_cu[filter ? 3 : vox ? 1 : (ctx->nn_mode == 2 ? 2 : 0)];
             // tiles of the hand-out: 64 points per wave, or the 1024-point chunks of a LIST pass (one block per chunk)
             const int64_t tiles = mode == PCR_NN_LIST ? (a.n + PCR_LIST_CHUNK - 1) / PCR_LIST_CHUNK : (a.n + 63) / 64;
             const int64_t need = mode == PCR_NN_LIST ? tiles : (tiles + 3) / 4;
@@ -591,6 +640,13 @@ static pcr_status pass_enqueue(Pass *ps) {
                 pcr_dev_launch_coop(nn_grid, ctx->stream, a);
             } else if (!vox) {
                 launch_nn_scan<0>(mode, ps->t->cs_h != nullptr, ps->a.sched_local, nn_grid, ctx->stream, a);
+            } else if (filter) {
+                if (++ctx->filter_stamp == 0) {                    // (wrapped after 2^32 passes: start over)
+                    HIP_TRY(hipMemsetAsync(a.pending, 0, 4, ctx->stream));
+                    ctx->filter_stamp = 1;
+                }
+                ps->a.stamp = ctx->filter_stamp;
+                launch_nn_filter(ps->t->filter->cs_h != nullptr, ps->a.sched_local, nn_grid, ctx->stream, a);
             } else if (ps->t->gd.rowocc != nullptr && (ctx->vox_occ >= 0 ? ctx->vox_occ != 0 : a.md_d / ps->t->gd.h + 2.0 >= 5.0)) {
                 launch_nn_scan<2>(mode, false, ps->a.sched_local, nn_grid, ctx->stream, a);
             } else {

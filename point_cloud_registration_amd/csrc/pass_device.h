@@ -47,6 +47,13 @@ struct LinArgs {
     double md_d;       // gate, float64 compare (voxel targets)
     float bound2_f;    // search bound (squared), slightly above the gate
     double bound2_d;
+    // float32 filter of a plain centroid search (nn_point_filter; gf / pts then describe the index over the ROUNDED centroids)
+    const uint32_t *cs_f;   // its cell_start
+    float band_f;           // how far rounding to float32 may move a centroid (metres); 0 = no filter
+    float mu_ff;            // tracking margin of the filter search: 2 band + 3e-5 of the bound
+    float bound2_ff;        // its search bound (squared): the float64 bound + band, a little more
+    uint32_t *pending;      // one word: the stamp of the last filter pass that left PCR_PENDING entries in nn_j (k_nn_fix)
+    uint32_t stamp;         // this pass' stamp (increasing per context)
     unsigned flags;
     int nblocks;
     double *partials;  // [nblocks + 8][32]
@@ -527,6 +534,55 @@ __device__ __forceinline__ void nn_point(const LinArgs &a, const PoseK &P, const
             a.nn_j[i] = ok ? bj : PCR_NONE;
         }
     }
+}
+
+// Plain centroid search, float32 FILTER + float64 check (round 3).  The float64 ring search costs 1.6x the float32
+// one over the same centroids (32-byte records, half-rate arithmetic, no packed key).  So: a float32 TRACKING search over
+// the centroids rounded to float32 (margin mu_ff, a fraction of a millimetre) returns a winner and a lower bound lbq on
+// the float32-space distance of every other rounded centroid; rounding moved no centroid by more than `band`, so every
+// other TRUE centroid is farther than lbq - band.  The winner's float64 distance d is computed exactly as the float64
+// search computes it (nn_test<double>); if (lbq - band)^2 > d the float64 search would have returned this winner --
+// strictly closer than everything else, so the tie rule is not involved.  "Nothing within the inflated bound" is
+// certified the same way.  A lane that cannot certify (two centroids within ~0.1 mm of the same distance, duplicates)
+// is left to k_nn_fix, the launch behind this one: nn_j = PCR_PENDING, and the pass' stamp goes into a.pending so that
+// k_nn_fix returns at once when no lane asked (it runs the float64 search for the pending points: identical results by
+// construction, `test_centroid_filter_is_exact`).  Inlining that search here instead cost 96 VGPRs + 140 spilled SGPRs.
+#define PCR_PENDING 0xfffffffeu
+template <int HALO>
+__device__ __forceinline__ void nn_point_filter(const LinArgs &a, const PoseK &P, int64_t i) {
+    const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
+    float tx, ty, tz;
+    xform(P, x, y, z, tx, ty, tz);
+    uint32_t fj = PCR_NONE, fo = PCR_NONE;
+    float best = a.bound2_ff;
+    NNTrack<float> tk;
+    nn_track_init<float>(tk, a.bound2_ff, a.mu_ff);
+    nn_search<float, PtF, false, false, HALO != 0, true>(a.gf, a.pts, a.cs_f, tx, ty, tz, a.bound2_ff, best, fj, fo, nullptr, &tk);
+    uint32_t out = PCR_NONE;       // nothing within bound + band among the rounded centroids: nothing within the gate
+    if (fo != PCR_NONE) {
+        const PtD m = a.means[fo];
+        const double dx = (double)tx - m.x, dy = (double)ty - m.y, dz = (double)tz - m.z;
+        const double d = (dx * dx + dy * dy) + dz * dz;
+        const float lbq = __builtin_sqrtf(fminf(tk.second, tk.pmin)) * 0.99999f - a.band_f;
+        const bool cert = lbq > 0.f && (double)lbq * (double)lbq > d * 1.000001;
+        out = __builtin_sqrt(d) < a.md_d ? fo : PCR_NONE;
+        if (!cert) {
+            out = PCR_PENDING;
+            atomicMax(a.pending, a.stamp);
+        }
+    }
+    a.nn_j[i] = out;
+}
+
+// the float64 search for the points nn_point_filter could not certify
+__device__ __forceinline__ void nn_point_fix(const LinArgs &a, const PoseK &P, int64_t i) {
+    float tx, ty, tz;
+    xform(P, a.sx[i], a.sy[i], a.sz[i], tx, ty, tz);
+    double bd = a.bound2_d;
+    uint32_t bj = PCR_NONE, bo = PCR_NONE;
+    nn_search<double, PtD, false, false, false, false, false>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz,
+                                                              a.bound2_d, bd, bj, bo);
+    a.nn_j[i] = (bo != PCR_NONE && __builtin_sqrt(bd) < a.md_d) ? bj : PCR_NONE;
 }
 
 // ---- fold the per-block partials in a fixed order and emit the 29-vector ---------------------

@@ -198,10 +198,11 @@ struct pcr_context {
     double *d_trace = nullptr;
     int trace_cap = 0;
     int variant = 0;
-    int nn_mode = 0;             // 0 per-lane search; 2 wave-cooperative (developer builds)
+    int nn_mode = 0;             // 0 per-lane search; 2 wave-cooperative (developer builds); 3 = 0 without the float32 filter of the centroid search
     // certified reuse of the previous pass' matches (see kernels.hip: choose_nn_mode)
     double local_frac = 0.35;    // block-local tile hand-out when the scan moved less than this x cell size (PCR_LOCAL_FRAC)
     double voxel_cell_mult = 2.0; // PCR_VOXEL_CELL_MULT: centroid grid cell edge in voxels
+    int vox_filter = 1;          // PCR_VOX_FILTER=0: plain passes search the centroids in float64 (no float32 filter)
     int vox_occ = -1;            // PCR_VOX_OCC (developer): force the centroid search's row-bitmap variant on / off; -1 = by gate / cell ratio
     int tile_local = -1;         // PCR_TILE_LOCAL (developer): force the hand-out policy of k_nn_scan; -1 = automatic
     int reuse = 1;               // 0 off, 1 automatic, 2 forced (track + list whenever the state allows: tests)
@@ -210,7 +211,8 @@ struct pcr_context {
     uint64_t next_serial = 1;    // targets get unique serial numbers (validity of a scan's previous matches)
     bool fuse_finalize = true;   // k_reduce_finalize (PCR_FUSE_FINALIZE=0: k_reduce + k_finalize)
     uint32_t *d_tile_ctr = nullptr;     // per-XCD dynamic tile counters of k_nn_scan
-    int nn_blocks_per_cu[3] = {4, 4, 4};   // resident 256-thread blocks per CU of k_nn_scan<0/1>, k_nn_coop
+    int nn_blocks_per_cu[4] = {4, 4, 4, 4};   // resident 256-thread blocks per CU of k_nn_scan<0/1>, k_nn_coop, k_nn_filter
+    uint32_t filter_stamp = 0;          // stamp of the last k_nn_filter pass (k_nn_fix)
     // profiling
     bool prof_on = false;
     int prof_period = 1;        // events around every prof_period-th pass (1 = every pass)
@@ -255,6 +257,11 @@ struct pcr_target {
     double *st_mean = nullptr, *st_cov = nullptr, *st_norm = nullptr, *st_icov = nullptr;
     int64_t *st_counts = nullptr, *st_keys = nullptr;
     double voxel_size = 0;
+    // float32 filter of the centroid search (k_nn_filter): a point index over the float32-ROUNDED centroids, in the
+    // order of `means` (its "original index" is the cell-sorted index of the centroid); filter_band bounds how far a
+    // centroid moves when it is rounded to float32 (metres).  nullptr: no filter (coordinates too large, PCR_VOX_FILTER=0)
+    pcr_target *filter = nullptr;
+    double filter_band = 0;
 };
 
 struct pcr_scan {
@@ -297,7 +304,8 @@ void pcr_scan_free(pcr_scan *s, void *p);      // one block back to the cache (n
 #define PCR_NN_LIST 2     // k_certify proves most of the old matches still exact; tracking search of the rest
 
 // ---- index_build.hip
-pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n, float cell_hint, pcr_target *t);
+pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n, float cell_hint, pcr_target *t, bool use_env = true);
+pcr_status pcr_build_centroid_filter(pcr_context *ctx, pcr_target *t);
 pcr_status pcr_build_centroid_grid(pcr_context *ctx, const double *d_mean, int64_t n, double cell, pcr_target *t);
 pcr_status pcr_count_nonfinite(pcr_context *ctx, const void *d_xyz, int is_f64, int64_t n, int64_t *count);
 pcr_status pcr_sort_scan(pcr_context *ctx, const float *d_xyz, int64_t n, unsigned flags, pcr_scan *s);

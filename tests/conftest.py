@@ -91,6 +91,7 @@ PIPELINES = {
     "reuse": dict(variant=1, fuse_finalize=1, nn_mode=0, reuse=2),      # ... certified reuse of the previous matches FORCED on every pass it can run on
     "noreuse": dict(variant=1, fuse_finalize=1, nn_mode=0, reuse=0),    # ... and off
     "coop": dict(variant=1, fuse_finalize=1, nn_mode=2, reuse=1),       # wave-cooperative search (k_nn_coop)
+    "nofilter": dict(variant=1, fuse_finalize=1, nn_mode=3, reuse=1),   # centroid searches in float64 throughout (no float32 filter + check)
     "unfused": dict(variant=1, fuse_finalize=0, nn_mode=0, reuse=2),    # k_nn_scan + k_reduce + k_finalize
     "onekernel": dict(variant=0, fuse_finalize=1, nn_mode=0, reuse=1),  # k_linearize_finalize (what small scans run)
     "onekernel_unfused": dict(variant=0, fuse_finalize=0, nn_mode=0, reuse=1),   # k_linearize + k_finalize

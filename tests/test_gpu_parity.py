@@ -941,3 +941,49 @@ def test_quirk_q6_float64_target(capi, g9):
         H, g, e2 = p.calc_H_g_e2(T, g9["source"])
         assert rel_H(H, g9[f"{tag}_plane_H"]) < TOL_REF
     assert _pose_close(p.align(g9["source"], np.eye(4)), g9["align_final"])
+
+
+@pytest.mark.parametrize("offset", [0.0, 3.0e4, 2.0e7])
+@pytest.mark.parametrize("vs", [1.0, 2.0])
+def test_centroid_filter_is_exact(capi, orc, ctx, vs, offset):
+    """Plain passes over a voxel target run a float32 filter search over the rounded centroids and check the winner in
+    float64 (k_nn_filter / k_nn_fix); whatever it cannot certify is searched in float64.  The 29 sums must be
+    BIT-identical to the float64-only pipeline (nn_mode 3) -- same matches, same reduce kernel -- and match the oracle:
+    ordinary poses, a tight gate, queries ON centroids, duplicated centroids (exact ties -> smaller index), and
+    coordinates large enough that the filter certifies little (3e4 m) or is not built at all (2e7 m)."""
+    from point_cloud_registration_amd.synthetic import street, perturbed_scan
+    target = street(300_000, seed=11).astype(np.float64) + np.array([offset, -offset, 0.0])
+    scan, T_true = perturbed_scan(target.astype(np.float32), 40_000, seed=12)
+    o_vox = orc.TargetVoxels(target, vs)
+    mean, norm, icov = o_vox.mean.copy(), o_vox.norm.copy(), o_vox.icov.copy()
+    nv = mean.shape[0]
+    assert nv > 500
+    # duplicated centroids: rows 0..49 again at the end (exact distance ties between distinct indices)
+    mean = np.concatenate([mean, mean[:50]]); norm = np.concatenate([norm, norm[:50]]); icov = np.concatenate([icov, icov[:50]])
+    g_vox = capi.Target.voxels_from_stats(ctx, mean, norm, icov, vs)
+    assert (g_vox.index_info()["halo_records"] > 0) == (offset < 1e6)      # the filter index exists / is refused
+    # queries: the scan, plus points exactly on centroids and exactly between two neighbouring centroids
+    on = mean[:2000].astype(np.float32)
+    mid = (0.5 * (mean[:2000] + mean[1:2001])).astype(np.float32)
+    src = np.ascontiguousarray(np.concatenate([scan, on, mid]), dtype=np.float32)
+    sc = capi.Scan(ctx, src)
+    poses = [np.eye(4), T_true]
+    T = np.eye(4); T[:3, 3] = [0.3, -0.2, 0.1]
+    poses.append(T)
+    for T in poses:
+        for md in (2.0, 0.3, 25.0):
+            outs = {}
+            for name, mode in (("filter", 0), ("f64", 3)):
+                with ctx.pipeline(variant=1, fuse_finalize=1, nn_mode=mode, reuse=0):
+                    outs[name] = [capi.linearize(g_vox, sc, k, T, md).copy() for k in (capi.VPLANE, capi.NDT)]
+            for a, b in zip(outs["filter"], outs["f64"]):
+                assert np.array_equal(a, b), (vs, offset, md, a[28], b[28])
+    # and the matches themselves against brute force, through the oracle's sums on the un-duplicated target
+    g_ref = capi.Target.voxels_from_stats(ctx, o_vox.mean, o_vox.norm, o_vox.icov, vs)
+    for kind in (capi.VPLANE, capi.NDT):
+        with ctx.pipeline(variant=1, fuse_finalize=1, nn_mode=0, reuse=0):
+            out = capi.linearize(g_ref, sc, kind, T_true, 2.0)
+        H, g, e2, cnt = capi.unpack29(out)
+        Ho, go, e2o, cnto = orc.calc_H_g_e2(kind, o_vox, T_true, src, 2.0, with_count=True)
+        assert cnt == cnto
+        assert rel_H(H, Ho) < 1e-9
