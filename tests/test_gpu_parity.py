@@ -403,6 +403,7 @@ def test_profile_counters(capi, ctx, g2, pipeline):
             "reuse": dict(nn=5, reduce=5, finalize=0, linearize=0, certify=3),     # full, tracking, 3 x certify + list
             "noreuse": dict(nn=5, reduce=5, finalize=0, linearize=0, certify=0),
             "coop": dict(nn=5, reduce=5, finalize=0, linearize=0),
+            "nofilter": dict(nn=5, reduce=5, finalize=0, linearize=0),
             "unfused": dict(nn=5, reduce=5, finalize=5, linearize=0, certify=3),
             "onekernel": dict(nn=0, reduce=0, finalize=0, linearize=5),
             "onekernel_unfused": dict(nn=0, reduce=0, finalize=5, linearize=5)}[pipeline]
@@ -987,3 +988,27 @@ def test_centroid_filter_is_exact(capi, orc, ctx, vs, offset):
         Ho, go, e2o, cnto = orc.calc_H_g_e2(kind, o_vox, T_true, src, 2.0, with_count=True)
         assert cnt == cnto
         assert rel_H(H, Ho) < 1e-9
+
+
+def test_centroid_filter_everything_pending(capi, orc, ctx):
+    """EVERY centroid duplicated: every matched point is an exact tie the float32 filter cannot certify, so k_nn_fix
+    searches all 1.3 M of them in float64; then a small scan, then the large one again (the stamps of consecutive passes).
+    Bit-identical to the float64-only pipeline each time."""
+    from point_cloud_registration_amd.synthetic import street, perturbed_scan
+    target = street(300_000, seed=21)
+    o_vox = orc.TargetVoxels(target, 1.0)
+    mean = np.concatenate([o_vox.mean, o_vox.mean]); norm = np.concatenate([o_vox.norm, o_vox.norm])
+    icov = np.concatenate([o_vox.icov, o_vox.icov])
+    g_vox = capi.Target.voxels_from_stats(ctx, mean, norm, icov, 1.0)
+    big = np.ascontiguousarray(np.tile(perturbed_scan(target, 130_000, seed=22)[0], (10, 1)), dtype=np.float32)
+    small = np.ascontiguousarray(big[:50_000])
+    T = np.eye(4); T[:3, 3] = [0.05, -0.03, 0.02]
+    for src in (big, small, big):
+        sc = capi.Scan(ctx, src)
+        outs = []
+        for mode in (0, 3):
+            with ctx.pipeline(variant=1, fuse_finalize=1, nn_mode=mode, reuse=0):
+                outs.append([capi.linearize(g_vox, sc, k, T, 2.0).copy() for k in (capi.VPLANE, capi.NDT)])
+        for a, b in zip(*outs):
+            assert a[28] > 0.5 * len(src)
+            assert np.array_equal(a, b)
