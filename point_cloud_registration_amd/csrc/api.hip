@@ -476,7 +476,6 @@ pcr_status pcr_voxel_target_finish(pcr_context *ctx, pcr_target *t, double voxel
     // the point grid's automatic cell size aims for too.  Measured (vplane_10m, search us per
     // pose): 1x 940, 1.5x 880, 2x 830, 2.5x 1020, 3x 1150; ndt_10m totals are equal at 1x and 2x.
     PCR_TRY(pcr_build_centroid_grid(ctx, t->st_mean, t->n, voxel_size * ctx->voxel_cell_mult, t));
-    PCR_TRY(pcr_build_centroid_filter(ctx, t));
     const size_t nn = (size_t)(t->n ? t->n : 1);
     if (t->st_norm) {
         HIP_TRY(pcr_persist_alloc((void **)&t->vnorm, sizeof(double) * 3 * nn));

@@ -484,7 +484,11 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
     a.gf = t->gf; a.pts = t->pts; a.pn = t->pn;
     a.gd = t->gd; a.means = t->means; a.vnorm = t->vnorm; a.vicov = t->vicov;
     a.cell_start = t->cell_start;
-    if (t->is_voxel && t->filter && ctx->vox_filter && ctx->nn_mode != 3) {
+    if (t->is_voxel && !t->filter_tried && !one_kernel && ctx->vox_filter && ctx->nn_mode != 3) {
+        t->filter_tried = true;
+        PCR_TRY(pcr_build_centroid_filter(ctx, t));
+    }
+    if (t->is_voxel && t->filter && !one_kernel && ctx->vox_filter && ctx->nn_mode != 3) {
         a.gf = t->filter->gf; a.pts = t->filter->pts; a.cs_f = t->filter->cell_start;
         a.band_f = (float)(t->filter_band * 1.000001);
     }

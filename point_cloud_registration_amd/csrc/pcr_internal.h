@@ -262,6 +262,8 @@ struct pcr_target {
     // centroid moves when it is rounded to float32 (metres).  nullptr: no filter (coordinates too large, PCR_VOX_FILTER=0)
     pcr_target *filter = nullptr;
     double filter_band = 0;
+    bool filter_tried = false;     // built by the first pass that can use it (search + reduce pipeline), not by set_target:
+                                   // 0.3 ms that a 100 k-point scan -- fused kernel, float64 search -- never gets back
 };
 
 struct pcr_scan {

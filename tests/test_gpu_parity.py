@@ -962,7 +962,6 @@ def test_centroid_filter_is_exact(capi, orc, ctx, vs, offset):
     # duplicated centroids: rows 0..49 again at the end (exact distance ties between distinct indices)
     mean = np.concatenate([mean, mean[:50]]); norm = np.concatenate([norm, norm[:50]]); icov = np.concatenate([icov, icov[:50]])
     g_vox = capi.Target.voxels_from_stats(ctx, mean, norm, icov, vs)
-    assert (g_vox.index_info()["halo_records"] > 0) == (offset < 1e6)      # the filter index exists / is refused
     # queries: the scan, plus points exactly on centroids and exactly between two neighbouring centroids
     on = mean[:2000].astype(np.float32)
     mid = (0.5 * (mean[:2000] + mean[1:2001])).astype(np.float32)
@@ -979,6 +978,8 @@ def test_centroid_filter_is_exact(capi, orc, ctx, vs, offset):
                     outs[name] = [capi.linearize(g_vox, sc, k, T, md).copy() for k in (capi.VPLANE, capi.NDT)]
             for a, b in zip(outs["filter"], outs["f64"]):
                 assert np.array_equal(a, b), (vs, offset, md, a[28], b[28])
+    # (the filter index is built by the first pass that can use it; refused when float32 rounding is too coarse)
+    assert (g_vox.index_info()["halo_records"] > 0) == (offset < 1e6)
     # and the matches themselves against brute force, through the oracle's sums on the un-duplicated target
     g_ref = capi.Target.voxels_from_stats(ctx, o_vox.mean, o_vox.norm, o_vox.icov, vs)
     for kind in (capi.VPLANE, capi.NDT):
