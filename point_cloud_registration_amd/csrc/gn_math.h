@@ -147,3 +147,19 @@ PCR_HD static inline int gn_choose_nn_mode(int reuse, int have_prev, int track_v
     if (prev_motion >= 0.0 && prev_motion < 8.0 * tau_len && motion > 0.3 * prev_motion) return 1;
     return 0;
 }
+
+// ---- float32 filter of the float64 centroid search (pass_device.h: nn_point_filter) -----------------------------
+// How far rounding the three coordinates of a point to float32 can move it, for coordinates up to `maxabs` in
+// magnitude: half an ulp = 2^-24 relative per coordinate, sqrt(3) for the vector, 1 % on top.
+PCR_HD static inline double gn_filter_band(double maxabs) {
+    return 1.7321 * 1.01 * maxabs * 5.9604644775390625e-8 + 1e-30;
+}
+// Bound (squared) and tracking margin of the float32 search that goes with a float64 search bound: the bound grows by
+// the band (a rounded centroid beyond it is a true centroid beyond the float64 bound); the margin must leave, after the
+// 0.99999 safety factor on the reported lower bound (<= 1e-5 of the bound) and the band on either side, a positive gap:
+// lbq = (sqrt(best) + mu) * 0.99999 - band  >  sqrt(best) + band  >=  the winner's float64 distance.
+PCR_HD static inline void gn_filter_bounds(double band, double bound, float *bound2_ff, float *mu_ff) {
+    const double bf = (bound + band) * 1.00002;
+    *bound2_ff = (float)(bf * bf * 1.000001);
+    *mu_ff = (float)(2.0 * band + 3e-5 * bf);
+}

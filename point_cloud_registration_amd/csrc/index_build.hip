@@ -13,6 +13,7 @@
 #include <cmath>
 
 #include "nn_device.h"
+#include "gn_math.h"
 
 // ---- bounding box ---------------------------------------------------------------------------
 __device__ __forceinline__ unsigned f2ord(float f) {
@@ -591,8 +592,7 @@ pcr_status pcr_build_centroid_filter(pcr_context *ctx, pcr_target *t) {
         maxabs = fmax(maxabs, fabs(lo[i]));
         maxabs = fmax(maxabs, fabs(lo[i] + ext[i]));
     }
-    // half an ulp per coordinate = 2^-24 relative; sqrt(3) for the vector; 1 % on top
-    const double band = 1.7321 * 1.01 * maxabs * 5.9604644775390625e-8 + 1e-30;
+    const double band = gn_filter_band(maxabs);
     if (!(band <= 0.01 * g.h)) return PCR_OK;
     DevBuf<float> xyz;
     HIP_TRY(xyz.alloc((size_t)t->n * 3));

@@ -541,9 +541,7 @@ static void pass_set_host_pose(Pass *ps, const double T[16]) {
 // bound and margin of the float32 filter search (nn_point_filter) that go with a float64 search bound
 static void set_filter_bound(LinArgs &a, double bound) {
     if (a.band_f <= 0.f) return;
-    const double bf = (bound + (double)a.band_f) * 1.00002;
-    a.bound2_ff = (float)(bf * bf * 1.000001);
-    a.mu_ff = (float)(2.0 * (double)a.band_f + 3e-5 * bf);
+    gn_filter_bounds((double)a.band_f, bound, &a.bound2_ff, &a.mu_ff);
 }
 
 // What the search of a pass does (gn_math.h: gn_choose_nn_mode) and the search bound that goes with it: a tracking

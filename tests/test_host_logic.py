@@ -269,3 +269,78 @@ int main() {
             choose(1, True, False, 0.001, 0.02, tau), choose(0, True, True, 0, 0, tau), choose(2, True, False, 1, 1, tau),
             choose(2, True, True, 1, 1, tau), choose(1, False, True, 0, 0, tau)]
     assert [int(v) for v in out[1:]] == want
+
+
+def _filter_consts(maxabs, bound):
+    """gn_filter_band / gn_filter_bounds (csrc/gn_math.h) through g++: the numbers the library computes."""
+    import os
+    import subprocess
+    import tempfile
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = r"""
+#include <stdio.h>
+#include <stdlib.h>
+#include "gn_math.h"
+int main(int argc, char **argv) {
+    const double band = gn_filter_band(atof(argv[1]));
+    const float band_f = (float)(band * 1.000001);
+    float b2, mu;
+    gn_filter_bounds((double)band_f, atof(argv[2]), &b2, &mu);
+    printf("%.9g %.9g %.9g\n", (double)band_f, (double)b2, (double)mu);
+    return 0;
+}
+"""
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.cpp"), "w").write(src)
+        subprocess.run(["g++", "-O1", "-I", os.path.join(repo, "point_cloud_registration_amd", "csrc"), os.path.join(d, "t.cpp"),
+                        "-o", os.path.join(d, "t")], check=True, capture_output=True)
+        out = subprocess.run([os.path.join(d, "t"), repr(float(maxabs)), repr(float(bound))], capture_output=True, text=True, check=True)
+    return [np.float32(v) for v in out.stdout.split()]
+
+
+@pytest.mark.parametrize("maxabs", [300.0, 3.0e4])
+def test_centroid_filter_certificate(maxabs):
+    """The inequality behind k_nn_filter (csrc/pass_device.h: nn_point_filter), restated on the CPU with the library's own
+    constants: a float32 search over the ROUNDED centroids nominates a winner and reports a lower bound on the float32-space
+    distance of every other rounded centroid; whenever `(lbq * 0.99999 - band)^2 > d64 * 1.000001` holds, the float64 search
+    (distance, then smaller index) must return that same winner -- for ordinary clouds, near-ties from 1e-7 to 1e-3 m,
+    exact duplicates, coordinates at the edge of the box.  The restatement grants the device the LARGEST bound it could
+    report (the true second-smallest distance, capped by the tracking margin), i.e. the most permissive certificate."""
+    rng = np.random.default_rng(int(maxabs))
+    band, bound2_ff, mu = _filter_consts(maxabs, 2.0 * (1 + 1e-6))
+    assert band <= 0.01 * 1.0 or maxabs > 1e4            # (1 m cells: the filter is built at 300 m; 3e4 m is a 0.5 % case)
+    n_c, n_q = 4000, 3000
+    base = rng.uniform(-1, 1, 3) * (maxabs - 40.0)
+    cent = base + rng.uniform(-20, 20, (n_c, 3))
+    cent[:, 2] = base[2] + rng.uniform(-2, 2, n_c)
+    q = (base + rng.uniform(-20, 20, (n_q, 3)) * [1, 1, 0.1]).astype(np.float32)
+    # adversarial pairs: for the first 600 queries, two centroids at distances r and r + eps in random directions
+    k = 600
+    for i in range(k):
+        r = rng.uniform(0.01, 1.5); eps = 10.0 ** rng.uniform(-7, -3)
+        u, v = rng.normal(size=3), rng.normal(size=3)
+        cent[2 * i] = q[i].astype(np.float64) + u / np.linalg.norm(u) * r
+        cent[2 * i + 1] = q[i].astype(np.float64) + v / np.linalg.norm(v) * (r + eps)
+    cent[3000:3050] = cent[2000:2050]                  # exact duplicates
+    c32 = cent.astype(np.float32)
+    assert np.max(np.linalg.norm(c32.astype(np.float64) - cent, axis=1)) <= float(band)
+    n_cert = n_pend = 0
+    for i in range(n_q):
+        d32 = ((q[i] - c32) ** 2).sum(1, dtype=np.float32)                     # float32 arithmetic, like dist2_f32 up to an ulp
+        order = np.lexsort((np.arange(n_c), d32))
+        w, best, second = order[0], d32[order[0]], d32[order[1]]
+        if not best < bound2_ff:
+            continue                                                            # nothing within the bound: certified "none"
+        lb2q = min(np.float32(second), (np.sqrt(best) + mu) ** 2)               # min(second, pmin)
+        lbq = np.float32(np.sqrt(np.float32(lb2q))) * np.float32(0.99999) - band
+        dd = q[i].astype(np.float64) - cent
+        d64 = (dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1]) + dd[:, 2] * dd[:, 2]
+        cert = lbq > 0 and float(lbq) * float(lbq) > d64[w] * 1.000001
+        if cert:
+            n_cert += 1
+            exact = np.lexsort((np.arange(n_c), d64))[0]
+            assert exact == w, (i, w, exact, d64[w], d64[exact], float(lbq))
+            assert np.sort(d64)[1] > d64[w]                                      # strictly closer than everything else
+        else:
+            n_pend += 1
+    assert n_cert > 0.7 * n_q and n_pend >= 1                                   # the certificate is not vacuous, nor always true
