@@ -11,8 +11,12 @@ Default workload = BASELINE.json configs[1]: Point-to-Plane ICP, B-01 stand-in t
 (``street(1_060_000, seed=0)``, the .pcd itself is absent from the reference checkout) vs a
 perturbed full-size scan; steps walk along a recorded Gauss-Newton trajectory.
 
-Multi-GPU (``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...``): one
-process per GPU, the target replicated, no data-path collective besides the 232-byte all-reduce.
+Multi-GPU: one process per GPU, the target replicated, no data-path collective besides the 232-byte
+all-reduce.  Either launch form works: ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...``
+(ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), or plain ``python bench.py --gpus N ...``, which re-executes
+itself under ``torch.distributed.run`` on 127.0.0.1 with a free port (``self_launch``).  ``--backend nccl`` (RCCL, the
+default) or ``gloo`` (host all-reduce: the agreed fallback transport, and what two ranks sharing ONE GPU use --
+``tests/test_gpu_bench_two_ranks.py``).
 ``--scaling weak`` (default): every rank owns a scan shard of the SAME size (its own perturbed scan);
 ``--scaling strong``: ONE scan of the configured size, rank r takes ``shard_scan(scan, r, N)``.
 
@@ -90,7 +94,47 @@ def parse():
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps passes; the median is reported")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--event-period", type=int, default=3, help="HIP events around every n-th pass")
+    ap.add_argument("--backend", default=os.environ.get("PCR_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the N > 1 plumbing (barrier, max over ranks); nccl = RCCL")
     return ap.parse_args()
+
+
+def effective_cpus():
+    """CPUs this process may actually use: the cgroup CPU-bandwidth quota (cpu.max, v2; cfs_quota, v1) capped by the
+    affinity mask -- NOT os.cpu_count(), which reports the 256 visible CPUs of a GPU box whose container has 16."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = min(n, max(int(quota), 1))
+    return max(n, 1)
+
+
+def self_launch(args):
+    """``python bench.py --gpus N`` without a launcher: become ``python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>`` (exec: same stdout,
+    same exit code).  Rank 0 of that run prints the one JSON line."""
+    import socket
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this pool (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")                     # what torchrun would set anyway; keeps the CPU quota for the ranks
+    env["PCR_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execvpe(cmd[0], cmd, env)
 
 
 def kernel_source_hash():
@@ -165,6 +209,8 @@ def make_scan(config, target, n_scan, family=None, seed=2):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        self_launch(args)                                      # does not return
     # stdout carries exactly ONE JSON line: route everything else that libraries print there (RCCL's
     # start-up banner, for one) to stderr by swapping the file descriptor until the final print
     sys.stdout.flush()
@@ -179,9 +225,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node "
-                             f"{args.gpus} bench.py --gpus {args.gpus} ...` (one process per GPU)")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
@@ -198,8 +241,9 @@ def main():
     comm = None
     use_comm = world > 1 or bool(os.environ.get("PCR_BENCH_FORCE_COMM"))     # the latter: 1-rank self-test
     if use_comm:
-        pdist.init_from_env("nccl")
-        comm = pdist.Communicator(ctx, in_library=True)
+        pdist.init_from_env(args.backend)
+        comm = pdist.Communicator(ctx, in_library=True)      # RCCL inside libpcr_hip.so; every rank agrees on a fallback
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"    # where the bench's own max-over-ranks tensor lives
 
     # ---- workload (synthetic; same target on every rank, own scan shard per rank) -------------
     t_setup = time.perf_counter()
@@ -269,7 +313,7 @@ def main():
         sync_all()
         dt = time.perf_counter() - t0
         if use_comm:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = float(t.item())
         return dt, o
@@ -334,6 +378,10 @@ def main():
             "config": {"workload": args.config, "description": desc, "kind": kind_name,
                        "target_points": int(n_target), "scan_points_per_gpu": int(sc.n),
                        "max_dist": max_dist, "voxel_size": voxel_size, "parallelism": f"scan-shard x{world}",
+                       "backend": (args.backend if use_comm else None),
+                       "allreduce_transport": (None if comm is None else
+                                               ("rccl-in-stream" if comm.in_library else f"host-{args.backend}")),
+                       "devices_visible": torch.cuda.device_count(),
                        "scan_points_job": int(n_scan_job),
                        "nn_index": {"cell": info["cell"], "dims": info["dims"], "occupied_cells": info["occupied"],
                                     "halo_m": info["halo"], "halo_records": info["halo_records"]},
@@ -470,6 +518,9 @@ def cpu_baseline(kind_name, target, scan, gpu_target, traj, max_dist, voxel_size
     """The CPU oracle (a port of the reference's NumPy path to C + OpenMP) on this box's host cores:
     the same calc_H_g_e2 on a bounded sample of the same workload."""
     from oracle import oracle as orc
+    cpus = effective_cpus()
+    team = int(os.environ.get("PCR_CPU_BASELINE_THREADS", cpus))
+    orc.set_threads(team)                             # the container's quota, not the 256 visible CPUs (oversubscribed + throttled)
     cap = 1_060_000                                   # bound the CPU work to ~10-30 s
     src = scan[:cap]
     tgt_pts = target
@@ -490,9 +541,10 @@ def cpu_baseline(kind_name, target, scan, gpu_target, traj, max_dist, voxel_size
     passes = done
     dt = time.perf_counter() - t0
     return {"value": round(src.shape[0] * passes / dt / 1e6, 4), "unit": "Mcorr/s",
-            "cores": orc.max_threads(), "host_cpus": os.cpu_count(), "kind": "port",
+            "cores": orc.max_threads(), "effective_cpus": cpus, "host_cpus_visible": os.cpu_count(), "kind": "port",
             "sample": f"{passes} passes of the same calc_H_g_e2 over {src.shape[0]} scan points "
-                      f"(oracle/pcr_oracle.c, OpenMP, exact grid NN); index build {t_build:.2f} s excluded"}
+                      f"(oracle/pcr_oracle.c, OpenMP team of {orc.max_threads()} = the cgroup CPU quota, exact grid NN); "
+                      f"index build {t_build:.2f} s excluded"}
 
 
 if __name__ == "__main__":

@@ -33,6 +33,11 @@ extern "C" {
 
 #define PCR_API __attribute__((visibility("default")))
 
+/* Bumped whenever an existing entry point changes its argument layout or the size of an array it writes
+ * (4: PCR_K_COUNT 5 -> 6, i.e. pcr_profile_read writes six entries).  A binding compares it with
+ * pcr_abi_version() of the library it loaded before calling anything else.                                   */
+#define PCR_ABI_VERSION 4
+
 typedef int pcr_status;
 enum {
     PCR_OK = 0,
@@ -72,12 +77,19 @@ typedef struct pcr_scan pcr_scan;
 /* ---- library / context ------------------------------------------------------------ */
 PCR_API const char *pcr_last_error(void);
 PCR_API const char *pcr_version(void);
+PCR_API int pcr_abi_version(void);
 PCR_API pcr_status pcr_device_count(int *count);
 PCR_API pcr_status pcr_context_create(int device, pcr_context **out);
 PCR_API pcr_status pcr_context_destroy(pcr_context *ctx);
 /* the context's HIP stream (hipStream_t as void*), for callers that order their own work */
 PCR_API pcr_status pcr_context_stream(pcr_context *ctx, void **stream);
 PCR_API pcr_status pcr_context_synchronize(pcr_context *ctx);
+/* Destroying targets and scans does not return their device memory to the HIP allocator: the blocks go to a
+ * per-context cache (hipFree synchronises the device, ~60 us each) and are handed out again to later targets /
+ * scans of a similar size.  At most PCR_CACHE_LIMIT_MB (default 1024) of idle blocks are kept; they are invisible to
+ * other allocators of the process (torch) until pcr_context_trim, which synchronises the stream and hipFree()s all
+ * of them (released_bytes may be NULL), or an allocation failure inside the library, which does the same.        */
+PCR_API pcr_status pcr_context_trim(pcr_context *ctx, uint64_t *released_bytes);
 
 /* ---- multi-GPU: one process per GPU, RCCL all-reduce of the 29 doubles per iteration ----
  * No reference counterpart (the reference is single-process).  Rank 0 obtains an id with
@@ -136,12 +148,23 @@ PCR_API pcr_status pcr_scan_create_device(pcr_context *ctx, const float *d_xyz, 
                                           pcr_scan **out);
 PCR_API pcr_status pcr_scan_size(pcr_scan *s, int64_t *n);
 PCR_API pcr_status pcr_scan_destroy(pcr_scan *s);
+/* Test / diagnostic seam: the correspondences the last search + reduce pass over this scan left in HBM -- one
+ * word per scan point IN THE SCAN'S DEVICE ORDER (Morton-sorted unless PCR_FLAG_NO_SCAN_SORT): the index of the
+ * matched record in the target's cell-sorted arrays, 0xffffffff = no correspondence.  Lets a test compare two
+ * search kernels match by match (KDTree.query's idx, kdtree.py:18-21 / voxel.py:171-179); fails when the scan
+ * has only run the fused small-scan kernel, which keeps its matches in registers.                            */
+PCR_API pcr_status pcr_scan_read_matches(pcr_scan *s, uint32_t *out);
 
 /* calc_H_g_e2(cur_T, source) takes the scan as an array on every call and is pure in it (registration.py:55-68):
  * the drop-in class keeps the device copy of the last scan and re-uploads when the CONTENT of the caller's array
  * changed.  pcr_hash64 is the content hash it uses: 64-bit, non-cryptographic, multi-threaded (12.7 MB in ~0.1 ms
  * on the GPU box's host; the value does not depend on the number of threads).                               */
 PCR_API pcr_status pcr_hash64(const void *data, uint64_t nbytes, uint64_t *out);
+/* CPUs the process may actually use: affinity mask capped by the cgroup CPU-bandwidth quota (cpu.max).  The hash
+ * pool above is sized from it; a host application should size ITS thread pools (OpenMP, BLAS) the same way -- on a
+ * 256-CPU box inside a 16-CPU container, pools sized by the visible CPUs get every thread of the process parked for
+ * the rest of a 100 ms scheduler period, the calling thread of pcr_linearize included.          */
+PCR_API int pcr_usable_cpus(void);
 
 /* ---- the hot path ---------------------------------------------------------------------
  * One calc_H_g_e2: transform (math_tools.py:111-113) -> exact 1-NN (kdtree.py:18-21 /
@@ -185,6 +208,9 @@ enum { PCR_K_LINEARIZE = 0, PCR_K_FINALIZE = 1, PCR_K_NN = 2, PCR_K_REDUCE = 3, 
 PCR_API pcr_status pcr_profile_enable(pcr_context *ctx, int on);
 PCR_API pcr_status pcr_profile_reset(pcr_context *ctx);
 PCR_API pcr_status pcr_profile_read(pcr_context *ctx, int64_t launches[PCR_K_COUNT], double total_ms[PCR_K_COUNT]);
+/* the same with the caller's array capacity stated (at most `capacity` entries are written; *count = PCR_K_COUNT of
+ * the library): what a binding compiled against an older header should call                                       */
+PCR_API pcr_status pcr_profile_read_n(pcr_context *ctx, int capacity, int64_t *launches, double *total_ms, int *count);
 /* grid geometry of a target's NN index: cell size, dims, occupied cells, points (or voxels) */
 PCR_API pcr_status pcr_target_index_info(pcr_target *t, double *cell, int64_t dims[3], int64_t *occupied, int64_t *n);
 /* point targets: margin (metres) and total records of the extended per-cell lists ring 0 searches (a cell's
@@ -192,6 +218,11 @@ PCR_API pcr_status pcr_target_index_info(pcr_target *t, double *cell, int64_t di
  * fraction of the cell edge, default 0.1, 0 = none).  Voxel targets: the same of the float32 filter index over
  * the rounded centroids (both 0: the target has no filter -- coordinates too large -- and searches in float64) */
 PCR_API pcr_status pcr_target_index_halo(pcr_target *t, double *halo, int64_t *records);
+/* voxel targets: the bound (metres) on how far rounding to float32 moved any centroid of the filter index -- what the
+ * float32 filter search of the centroid search (voxel.py:171-179) subtracts from its lower bounds before the float64
+ * check; 1.75 x 2^-24 x the largest coordinate magnitude of the centroid grid.  0 = no filter index (not built yet:
+ * the first search + reduce pass builds it; or refused: band > 1 % of the index cell)                               */
+PCR_API pcr_status pcr_target_filter_band(pcr_target *t, double *band);
 /* work counters of the NN search for one pose (point targets): out[0..3] = rings entered, row
  * segments loaded, rows pruned by arithmetic, candidates tested, summed over queries; out[4..7] = the
  * same with each wave's maximum charged to all 64 lanes (the cost under divergence); out[8..10] =

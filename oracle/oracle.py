@@ -43,6 +43,7 @@ def lib():
         build()
     L = C.CDLL(path)
     L.orc_max_threads.restype = C.c_int
+    L.orc_set_threads.argtypes = [C.c_int]
     L.orc_transform.argtypes = [_f64p, _f32p, C.c_int64, _f32p]
     L.orc_nn_brute_f32.argtypes = [_f32p, C.c_int64, _f32p, C.c_int64, _f32p, _i64p]
     L.orc_nn_brute_f64.argtypes = [_f64p, C.c_int64, _f32p, C.c_int64, _f64p, _i64p]
@@ -72,6 +73,11 @@ def lib():
 
 def max_threads():
     return int(lib().orc_max_threads())
+
+
+def set_threads(n):
+    """OpenMP team size of every later call (bench.py sets it to the container's CPU quota)."""
+    lib().orc_set_threads(int(n))
 
 
 def _c(a, dt):

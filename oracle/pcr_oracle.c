@@ -47,6 +47,14 @@ ORC_API int orc_max_threads(void) {
     return 1;
 #endif
 }
+/* size of the OpenMP team of every later call (bench.py: the container's CPU quota, not the visible CPUs) */
+ORC_API void orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 
 /* ------------------------------------------------------------------ A2: transform
  * math_tools.py:111-113 transform_points, called with T.astype(float32)

@@ -84,7 +84,14 @@ PROTOTYPES = {
     "pcr_get_reuse": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pcr_scan_reuse_stats": (C.c_int, [_vp, _f64p]),
     "pcr_hash64": (C.c_int, [_vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "pcr_target_filter_band": (C.c_int, [_vp, C.POINTER(C.c_double)]),
+    "pcr_usable_cpus": (C.c_int, []),
+    "pcr_abi_version": (C.c_int, []),
+    "pcr_context_trim": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "pcr_profile_read_n": (C.c_int, [_vp, C.c_int, _i64p, _f64p, C.POINTER(C.c_int)]),
+    "pcr_scan_read_matches": (C.c_int, [_vp, _vp]),
 }
+ABI_VERSION = 4                 # PCR_ABI_VERSION of the include/pcr.h this binding was written against
 
 
 class PcrError(RuntimeError):
@@ -152,6 +159,8 @@ def lib():
         fn = getattr(L, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if L.pcr_abi_version() != ABI_VERSION:
+        raise PcrError(f"{LIB_PATH} has ABI version {L.pcr_abi_version()}, this binding expects {ABI_VERSION}: rebuild it")
     _lib = L
     return L
 
@@ -243,10 +252,18 @@ class Context:
                     self.set_reuse(reuse)
                 yield self
             finally:
-                self.set_variant(prev["variant"])
-                self.set_fuse_finalize(prev["fuse_finalize"])
-                self.set_nn_mode(prev["nn_mode"])
-                self.set_reuse(prev["reuse"])
+                # restore everything that can be restored; a failing setter must not mask the body's own exception
+                # or leave the rest of the selection behind
+                errs = []
+                for fn, val in ((self.set_variant, prev["variant"]), (self.set_fuse_finalize, prev["fuse_finalize"]),
+                                (self.set_nn_mode, prev["nn_mode"]), (self.set_reuse, prev["reuse"])):
+                    try:
+                        fn(val)
+                    except Exception as exc:          # noqa: BLE001
+                        errs.append(exc)
+                import sys as _sys
+                if errs and _sys.exc_info()[0] is None:
+                    raise errs[0]
         return _cm()
 
     # -- RCCL
@@ -270,8 +287,16 @@ class Context:
     def profile_read(self):
         n = np.zeros(K_COUNT, np.int64)
         ms = np.zeros(K_COUNT, np.float64)
-        check(lib().pcr_profile_read(self.handle, n, ms))
-        return {KERNEL_NAMES[i]: (int(n[i]), float(ms[i])) for i in range(K_COUNT)}
+        cnt = C.c_int(0)
+        check(lib().pcr_profile_read_n(self.handle, K_COUNT, n, ms, C.byref(cnt)))
+        return {KERNEL_NAMES[i]: (int(n[i]), float(ms[i])) for i in range(min(K_COUNT, cnt.value))}
+
+    def trim(self):
+        """hipFree every idle block of the context's block cache (destroyed targets / scans leave up to 1 GiB there,
+        invisible to torch's allocator); returns the bytes released."""
+        b = C.c_uint64(0)
+        check(lib().pcr_context_trim(self.handle, C.byref(b)))
+        return int(b.value)
 
     def close(self):
         if getattr(self, "handle", None) and not _shutdown:
@@ -405,8 +430,10 @@ class Target:
         check(lib().pcr_target_index_info(self.handle, C.byref(cell), dims, C.byref(occ), C.byref(n)))
         halo, nh = C.c_double(0), C.c_int64(0)
         check(lib().pcr_target_index_halo(self.handle, C.byref(halo), C.byref(nh)))
+        band = C.c_double(0)
+        check(lib().pcr_target_filter_band(self.handle, C.byref(band)))
         return {"cell": cell.value, "dims": tuple(int(d) for d in dims), "occupied": occ.value, "n": n.value,
-                "halo": halo.value, "halo_records": nh.value}
+                "halo": halo.value, "halo_records": nh.value, "filter_band": band.value}
 
     def nn_query(self, q, r_max=np.inf):
         q = np.ascontiguousarray(q, dtype=np.float32)
@@ -465,6 +492,15 @@ class Scan:
         return {"passes_full": int(o[0]), "passes_track": int(o[1]), "passes_list": int(o[2]),
                 "list_searched": int(o[3]), "list_points": int(o[4]),
                 "last_mode": int(o[5]), "last_searched": int(o[6]), "last_motion": float(o[7])}
+
+    def matches(self):
+        """The correspondences of the last search + reduce pass over this scan (test / diagnostic seam): per scan
+        point in the scan's DEVICE order, the cell-sorted index of the matched target record, -1 = none."""
+        out = np.empty(self.n, np.uint32)
+        check(lib().pcr_scan_read_matches(self.handle, _ptr(out)))
+        m = out.astype(np.int64)
+        m[out == 0xFFFFFFFF] = -1
+        return m
 
     def close(self):
         if getattr(self, "handle", None) and not _shutdown:

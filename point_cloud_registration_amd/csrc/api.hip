@@ -23,7 +23,8 @@ void pcr_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *pcr_last_error(void) { return g_last_error.c_str(); }
-extern "C" const char *pcr_version(void) { return "pcr-hip 0.1 (gfx950)"; }
+extern "C" const char *pcr_version(void) { return "pcr-hip 0.4 (gfx950)"; }
+extern "C" int pcr_abi_version(void) { return PCR_ABI_VERSION; }
 
 extern "C" pcr_status pcr_device_count(int *count) {
     PCR_REQUIRE(count, "count is NULL");
@@ -36,9 +37,10 @@ extern "C" pcr_status pcr_device_count(int *count) {
 
 // ---- cache of temporaries (pcr_internal.h) ----------------------------------------------------------
 thread_local pcr_context *pcr_tls_ctx = nullptr;
-static const size_t PCR_CACHE_LIMIT = (size_t)1 << 30;        // at most 1 GiB of idle blocks per context
+typedef std::lock_guard<std::recursive_mutex> CacheLock;
 
 void *pcr_cache_get(pcr_context *ctx, size_t bytes, size_t *cap_out, bool tight) {
+    CacheLock lock(ctx->cache_mu);
     // smallest cached block that fits and is not wastefully large (<= 1.5x + 1 MiB; tight, for blocks that stay: 1.125x + 256 KiB)
     const size_t most = tight ? bytes + bytes / 8 + ((size_t)256 << 10) : bytes + bytes / 2 + ((size_t)1 << 20);
     int best = -1;
@@ -56,8 +58,9 @@ void *pcr_cache_get(pcr_context *ctx, size_t bytes, size_t *cap_out, bool tight)
 }
 
 void pcr_cache_put(pcr_context *ctx, void *p, size_t cap) {
-    if (cap > PCR_CACHE_LIMIT / 2 || ctx->cache.size() >= 256) { (void)hipFree(p); return; }
-    while (ctx->cache_bytes + cap > PCR_CACHE_LIMIT && !ctx->cache.empty()) {     // make room: drop the largest idle block
+    CacheLock lock(ctx->cache_mu);
+    if (cap > ctx->cache_limit / 2 || ctx->cache.size() >= 256) { (void)hipFree(p); return; }
+    while (ctx->cache_bytes + cap > ctx->cache_limit && !ctx->cache.empty()) {     // make room: drop the largest idle block
         int big = 0;
         for (int i = 1; i < (int)ctx->cache.size(); ++i) if (ctx->cache[i].first > ctx->cache[big].first) big = i;
         (void)hipFree(ctx->cache[big].second);
@@ -70,6 +73,7 @@ void pcr_cache_put(pcr_context *ctx, void *p, size_t cap) {
 }
 
 void pcr_cache_clear(pcr_context *ctx) {
+    CacheLock lock(ctx->cache_mu);
     for (auto &e : ctx->cache) (void)hipFree(e.second);
     ctx->cache.clear();
     ctx->cache_bytes = 0;
@@ -86,13 +90,17 @@ hipError_t pcr_persist_alloc(void **p, size_t bytes) {
         const hipError_t e = pcr_malloc_retry(p, cap);
         if (e != hipSuccess) { *p = nullptr; return e; }
     }
-    ctx->owned[*p] = cap;
+    {
+        CacheLock lock(ctx->cache_mu);
+        ctx->owned[*p] = cap;
+    }
     return hipSuccess;
 }
 
 void pcr_persist_free(pcr_context *ctx, void *p) {
     if (!p) return;
     if (ctx) {
+        CacheLock lock(ctx->cache_mu);
         auto it = ctx->owned.find(p);
         if (it != ctx->owned.end()) {
             const size_t cap = it->second;
@@ -133,9 +141,9 @@ void pcr_scan_free(pcr_scan *s, void *p) {
 
 hipError_t pcr_malloc_retry(void **p, size_t bytes) {
     hipError_t e = hipMalloc(p, bytes);
-    if (e != hipSuccess && pcr_tls_ctx && !pcr_tls_ctx->cache.empty()) {
+    if (e != hipSuccess && pcr_tls_ctx) {
         (void)hipGetLastError();
-        pcr_cache_clear(pcr_tls_ctx);
+        pcr_cache_clear(pcr_tls_ctx);                 // (a no-op on an empty cache)
         e = hipMalloc(p, bytes);
     }
     return e;
@@ -165,7 +173,12 @@ extern "C" pcr_status pcr_context_create(int device, pcr_context **out) {
     const char *v = getenv("PCR_VARIANT");
     if (v && *v) { const int vv = atoi(v); ctx->variant = vv == 0 ? 0 : (vv == 1 ? 1 : 2); }
     const char *nm = getenv("PCR_NN_MODE");
-    if (nm && *nm) ctx->nn_mode = atoi(nm);
+    if (nm && *nm) {
+        // the values pcr_set_nn_mode accepts; anything else (1 was a search variant of round 2) -> the shipped search
+        const int m = atoi(nm);
+        if (m == 0 || m == 2 || m == 3) ctx->nn_mode = m;
+        else fprintf(stderr, "[pcr] PCR_NN_MODE=%s is not a search mode of this library (0, 2, 3): using 0\n", nm);
+    }
     const char *ff = getenv("PCR_FUSE_FINALIZE");
     if (ff && *ff) ctx->fuse_finalize = atoi(ff) != 0;
     const char *lf = getenv("PCR_LOCAL_FRAC");
@@ -188,6 +201,9 @@ extern "C" pcr_status pcr_context_create(int device, pcr_context **out) {
     if (rt && *rt) ctx->reuse_tau = atof(rt);
     const char *rm = getenv("PCR_REUSE_MU");
     if (rm && *rm) ctx->reuse_mu = atof(rm);
+    if (ctx->reuse < 0 || ctx->reuse > 2) ctx->reuse = 1;
+    const char *cl = getenv("PCR_CACHE_LIMIT_MB");
+    if (cl && *cl && atof(cl) >= 0) ctx->cache_limit = (size_t)(atof(cl) * 1048576.0);
     *out = ctx;
     return PCR_OK;
 }
@@ -208,6 +224,17 @@ extern "C" pcr_status pcr_context_destroy(pcr_context *ctx) {
     if (ctx->d_tile_ctr) (void)hipFree(ctx->d_tile_ctr);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_context_trim(pcr_context *ctx, uint64_t *released_bytes) {
+    PCR_REQUIRE(ctx, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));      // idle blocks may still be read by queued kernels of their last owner
+    size_t before;
+    { CacheLock lock(ctx->cache_mu); before = ctx->cache_bytes; }
+    pcr_cache_clear(ctx);
+    if (released_bytes) *released_bytes = (uint64_t)before;
     return PCR_OK;
 }
 
@@ -361,11 +388,16 @@ extern "C" pcr_status pcr_profile_reset(pcr_context *ctx) {
     return PCR_OK;
 }
 
-extern "C" pcr_status pcr_profile_read(pcr_context *ctx, int64_t launches[PCR_K_COUNT], double total_ms[PCR_K_COUNT]) {
-    PCR_REQUIRE(ctx && launches && total_ms, "NULL argument");
+extern "C" pcr_status pcr_profile_read_n(pcr_context *ctx, int capacity, int64_t *launches, double *total_ms, int *count) {
+    PCR_REQUIRE(ctx && launches && total_ms && capacity >= 0, "NULL argument");
     prof_drain(ctx);
-    for (int i = 0; i < PCR_K_COUNT; ++i) { launches[i] = ctx->prof_launches[i]; total_ms[i] = ctx->prof_ms[i]; }
+    for (int i = 0; i < PCR_K_COUNT && i < capacity; ++i) { launches[i] = ctx->prof_launches[i]; total_ms[i] = ctx->prof_ms[i]; }
+    if (count) *count = PCR_K_COUNT;
     return PCR_OK;
+}
+
+extern "C" pcr_status pcr_profile_read(pcr_context *ctx, int64_t launches[PCR_K_COUNT], double total_ms[PCR_K_COUNT]) {
+    return pcr_profile_read_n(ctx, PCR_K_COUNT, launches, total_ms, nullptr);
 }
 
 // ---- small helpers ---------------------------------------------------------------------------
@@ -379,7 +411,9 @@ static pcr_status upload(pcr_context *ctx, const T *host, size_t count, DevBuf<T
     return PCR_OK;
 }
 
-static void target_free(pcr_target *t) {
+void pcr_target_release(pcr_target *t);
+static void target_free(pcr_target *t) { pcr_target_release(t); }
+void pcr_target_release(pcr_target *t) {
     if (!t) return;
     target_free(t->filter);
     void *ptrs[] = {t->cell_start, t->cell_seed, t->rowocc, t->cs_h, t->pts_h, t->j_h, t->pts, t->pn, t->means, t->vnorm, t->vicov,
@@ -559,6 +593,12 @@ extern "C" pcr_status pcr_target_index_halo(pcr_target *t, double *halo, int64_t
     return PCR_OK;
 }
 
+extern "C" pcr_status pcr_target_filter_band(pcr_target *t, double *band) {
+    PCR_REQUIRE(t && band, "NULL argument");
+    *band = (t->is_voxel && t->filter) ? t->filter_band : 0.0;
+    return PCR_OK;
+}
+
 extern "C" pcr_status pcr_target_destroy(pcr_target *t) {
     if (!t) return PCR_OK;
     (void)hipSetDevice(t->ctx->device);
@@ -594,6 +634,17 @@ extern "C" pcr_status pcr_scan_create(pcr_context *ctx, const float *xyz, int64_
 extern "C" pcr_status pcr_scan_size(pcr_scan *s, int64_t *n) {
     PCR_REQUIRE(s && n, "NULL argument");
     *n = s->n;
+    return PCR_OK;
+}
+
+// test / diagnostic seam: the correspondences the last search + reduce pass left behind, in the scan's device order
+extern "C" pcr_status pcr_scan_read_matches(pcr_scan *s, uint32_t *out) {
+    PCR_REQUIRE(s && (out || s->n == 0), "NULL argument");
+    if (!s->nn_j || s->nn_serial == 0) { pcr_set_error("no search + reduce pass has run over this scan"); return PCR_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    if (s->n == 0) return PCR_OK;
+    HIP_TRY(hipMemcpyAsync(out, s->nn_j, sizeof(uint32_t) * (size_t)s->n, hipMemcpyDeviceToHost, s->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
     return PCR_OK;
 }
 

@@ -7,9 +7,14 @@
 // Here: fixed 256 KiB chunks hashed in parallel by a small persistent pool of threads (wyhash-style 64x64->128
 // multiply-mix, four independent lanes per chunk), chunk digests folded in order -- the value does not depend on
 // the number of threads.  Not cryptographic; 64 bits: a collision needs ~2^32 distinct scans.
+#include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+
+#include <new>
 
 #include <atomic>
 #include <condition_variable>
@@ -118,14 +123,53 @@ struct Pool {
 std::mutex g_pool_mutex;
 Pool *g_pool = nullptr;
 
+// fork(): the child inherits g_pool but none of its threads (the next hash would wait for workers that do not exist),
+// and possibly g_pool_mutex locked by a thread that does not exist either.  The child starts over: a fresh
+// mutex, no pool (the parent's Pool object is leaked in the child -- its threads cannot be joined there).
+void hash_atfork_child() {
+    new (&g_pool_mutex) std::mutex();
+    g_pool = nullptr;
+}
+std::once_flag g_atfork_once;
+
+// CPUs this process may use: the affinity mask capped by the cgroup CPU-bandwidth quota (cpu.max of cgroup v2,
+// cfs_quota_us of v1).  A GPU box shows 256 CPUs to a container that may run 16: a pool sized by
+// hardware_concurrency() burns the quota and gets every thread of the process parked.
+int usable_cpus() {
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = c; }
+    double quota = -1.0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64]; double per = 0;
+        if (fscanf(f, "%63s %lf", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) quota = atof(q) / per;
+        fclose(f);
+    } else if (FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        double qv = -1, per = 0;
+        if (fscanf(fq, "%lf", &qv) != 1) qv = -1;
+        fclose(fq);
+        if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(fp, "%lf", &per) != 1) per = 0;
+            fclose(fp);
+        }
+        if (qv > 0 && per > 0) quota = qv / per;
+    }
+    if (quota > 0 && quota < n) n = (int)quota;
+    return n < 1 ? 1 : n;
+}
+
 }  // namespace
+
+// (exported for tests and for INTEGRATION.md's advice on sizing host thread pools)
+extern "C" int pcr_usable_cpus(void) { return usable_cpus(); }
 
 extern "C" pcr_status pcr_hash64(const void *data, uint64_t nbytes, uint64_t *out) {
     if (!out || (!data && nbytes)) return PCR_ERR_INVALID;
+    std::call_once(g_atfork_once, [] { (void)pthread_atfork(nullptr, nullptr, hash_atfork_child); });
     std::lock_guard<std::mutex> lk(g_pool_mutex);           // one hash at a time per process
     if (!g_pool) {
-        unsigned hw = std::thread::hardware_concurrency();
-        int n = hw >= 32 ? 15 : (hw >= 8 ? 7 : (hw >= 2 ? (int)hw - 1 : 0));
+        const int hw = usable_cpus();                       // the CPU quota, not the visible CPUs
+        int n = hw >= 32 ? 15 : (hw >= 16 ? 11 : (hw >= 8 ? 7 : (hw >= 2 ? hw - 1 : 0)));
         const char *e = getenv("PCR_HASH_THREADS");           // (developer: worker threads beside the caller)
         if (e && *e) { n = atoi(e); if (n < 0) n = 0; if (n > 63) n = 63; }
         g_pool = new Pool(n);                               // lives until the process exits

@@ -486,7 +486,12 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
     a.cell_start = t->cell_start;
     if (t->is_voxel && !t->filter_tried && !one_kernel && ctx->vox_filter && ctx->nn_mode != 3) {
         t->filter_tried = true;
-        PCR_TRY(pcr_build_centroid_filter(ctx, t));
+        // a failed build (out of memory, say) must not fail the pass: the float64 search needs no filter
+        if (pcr_build_centroid_filter(ctx, t) != PCR_OK || (t->filter && !(t->filter_band > 0))) {
+            (void)hipGetLastError();
+            pcr_target_release(t->filter);
+            t->filter = nullptr; t->filter_band = 0;
+        }
     }
     if (t->is_voxel && t->filter && !one_kernel && ctx->vox_filter && ctx->nn_mode != 3) {
         a.gf = t->filter->gf; a.pts = t->filter->pts; a.cs_f = t->filter->cell_start;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
 #include <unordered_map>
 #include <utility>
 #include <vector>
@@ -225,7 +226,12 @@ struct pcr_context {
     // RCCL
     void *comm = nullptr;
     int nranks = 1, rank = 0;
-    // cache of free device blocks (temporaries of the build paths): (capacity, pointer), total bytes
+    // cache of free device blocks (temporaries of the build paths): (capacity, pointer), total bytes.
+    // cache / cache_bytes / owned are guarded by cache_mu: a Scan / Target finalizer on one host thread (ctypes drops the
+    // GIL) may hand blocks back while another thread's pass or set_target takes blocks out.  Everything else
+    // of a context stays single-threaded by contract (include/pcr.h).
+    std::recursive_mutex cache_mu;
+    size_t cache_limit = (size_t)1 << 30;        // idle bytes kept at most (PCR_CACHE_LIMIT_MB; pcr_context_trim empties it)
     std::vector<std::pair<size_t, void *>> cache;
     size_t cache_bytes = 0;
     std::unordered_map<void *, size_t> owned;    // persistent blocks handed out by pcr_persist_alloc: capacity
@@ -304,6 +310,9 @@ void pcr_scan_free(pcr_scan *s, void *p);      // one block back to the cache (n
 #define PCR_NN_FULL 0     // plain exact search of every point
 #define PCR_NN_TRACK 1    // exact search of every point that also records the margin to the runner-up
 #define PCR_NN_LIST 2     // k_certify proves most of the old matches still exact; tracking search of the rest
+
+// ---- api.hip
+void pcr_target_release(pcr_target *t);      // frees a target and everything it owns (blocks back to its context's cache)
 
 // ---- index_build.hip
 pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n, float cell_hint, pcr_target *t, bool use_env = true);

@@ -244,28 +244,68 @@ def g7():
 
 def g9():
     """Quirk Q6: PlaneICP builds its tree on the ORIGINAL-dtype array (plane_icp.py:22) and gathers from the float32
-    copy (plane_icp.py:20,44).  A float64 target whose coordinates are not float32-representable: the reference's
-    H, g, e2 (float64 tree) and, for the record, how many neighbours differ from a float32 tree's."""
+    copy (plane_icp.py:20,44), so a float64 target is SEARCHED in float64.  The build casts to float32 for search and
+    gather alike.  This fixture makes the difference bite (the round-3 fixture recorded 0 differing
+    neighbours): coordinates ~500 m from the origin (float32 ulp 3e-5 m) that are not float32-representable, and two
+    scans -- "source": 2000 ordinary points in the frame of pose T (evaluated at T, at a nearby pose, and aligned);
+    "source_tie": the same 2000 points in the WORLD frame plus 800 queries placed within ~2e-5 m of the bisector plane
+    of a target point and its nearest neighbour, where rounding the target to float32 decides which of the two is
+    nearer -- evaluated at the IDENTITY, where the float32 transform is exact (at these coordinates the rounding of
+    the transform itself, 3e-5 m, would decide such ties as well and depends on the summation order of the matmul).
+    Stored: the reference's H, g, e2 under the float64 tree and under a float32 tree, the neighbour of every query
+    under both."""
+    from scipy.spatial import cKDTree
     base = mini_street(5000, seed=13).astype(np.float64)
     rng = np.random.default_rng(5)
-    target = base + rng.uniform(-3e-8, 3e-8, base.shape)          # below float32 resolution at these magnitudes
+    target = base + np.array([500.0, -300.0, 20.0]) + rng.uniform(-1e-5, 1e-5, base.shape)
     assert not np.array_equal(target, target.astype(np.float32).astype(np.float64))
-    pick = rng.choice(target.shape[0], 2000, replace=False)
     T = non_identity_T()
     Rinv = T[:3, :3].T
-    scan = ((Rinv @ target[pick].T).T - Rinv @ T[:3, 3] + rng.normal(0, 0.002, (2000, 3))).astype(np.float32)
+    pick = rng.choice(target.shape[0], 2000, replace=False)
+    world = target[pick] + rng.normal(0, 0.002, (2000, 3))
+    scan = ((Rinv @ world.T).T - Rinv @ T[:3, 3]).astype(np.float32)
+    # near-ties: the midpoint of a point and its nearest neighbour, moved along the pair by ~1e-5 m
+    d2, i2 = cKDTree(target).query(target, k=2)
+    tie = rng.choice(target.shape[0], 800, replace=False)
+    a, b = target[tie], target[i2[tie, 1]]
+    u = (b - a) / np.linalg.norm(b - a, axis=1, keepdims=True)
+    cand = (0.5 * (a + b) + u * rng.normal(0, 1e-5, (800, 1))).astype(np.float32)
+    # keep the near-ties that are NOT ties: best and runner-up at least 2e-6 (relative) apart under either tree, so that
+    # neither the tie rule of the backend nor the rounding of a float32 distance (6e-8) decides them -- only Q6 does
+    keep = np.ones(len(cand), bool)
+    for tree in (cKDTree(target), cKDTree(target.astype(np.float32).astype(np.float64))):
+        dd, _ = tree.query(cand.astype(np.float64), k=2)
+        keep &= (dd[:, 1] - dd[:, 0]) > 2e-6 * dd[:, 0]
+    cand = cand[keep]
+    print("G9: near-tie queries kept:", len(cand), "of 800")
+    scan_tie = np.concatenate([world.astype(np.float32), cand])
+    I = np.eye(4)
+    assert np.array_equal(ref.transform_points(I.astype(np.float32), scan_tie), scan_tie)      # exact at the identity
     picp = ref.PlaneICP(max_dist=0.8, k=10)
     picp.set_target(target)
-    out = {"target": target, "source": scan, "T": T, "max_dist": 0.8, "k": 10, "plane_normals": np.asarray(picp.normal)}
-    out["T_plane_H"], out["T_plane_g"], out["T_plane_e2"] = triple(picp.calc_H_g_e2(T, scan))
-    out["I_plane_H"], out["I_plane_g"], out["I_plane_e2"] = triple(picp.calc_H_g_e2(np.eye(4), scan))
-    st = ref.transform_points(T.astype(np.float32), scan)
-    d64, i64 = picp.kdtree.query(st)
     t32 = ref.KDTree(target.astype(np.float32))
-    d32, i32 = t32.query(st)
+    p32 = ref.PlaneICP(max_dist=0.8, k=10)                          # the same class on the float32 copy of the target
+    p32.set_target(target.astype(np.float32), t32, picp.normal)
+    out = {"target": target, "source": scan, "source_tie": scan_tie, "T": T, "max_dist": 0.8, "k": 10,
+           "plane_normals": np.asarray(picp.normal), "n_ordinary": np.int64(2000)}
+    # (at these coordinates the identity is 25 m off for "source": its second pose is T moved by a small step)
+    T_near = ref.plus(T, np.array([0.03, -0.02, 0.025, 2e-5, -3e-5, 2.5e-5]))
+    out["T_near"] = T_near
+    for tag, pose, sc in (("T", T, scan), ("N", T_near, scan), ("E", I, scan_tie)):
+        out[f"{tag}_plane_H"], out[f"{tag}_plane_g"], out[f"{tag}_plane_e2"] = triple(picp.calc_H_g_e2(pose, sc))
+        out[f"{tag}_plane_H_f32tree"], out[f"{tag}_plane_g_f32tree"], out[f"{tag}_plane_e2_f32tree"] = triple(p32.calc_H_g_e2(pose, sc))
+    d64, i64 = picp.kdtree.query(scan_tie)
+    d32, i32 = t32.query(scan_tie)
     out["nn_idx_f64_tree"], out["nn_idx_f32_tree"] = i64, i32
-    out["align_final"] = picp.align(scan, np.eye(4))
-    print("G9 (Q6): neighbours that differ between the float64 and the float32 tree:", int(np.sum(i64 != i32)), "of", len(i64))
+    out["nn_dist_f64_tree"], out["nn_dist_f32_tree"] = np.asarray(d64, np.float64), np.asarray(d32, np.float64)
+    st = ref.transform_points(T.astype(np.float32), scan)
+    assert np.array_equal(picp.kdtree.query(st)[1], t32.query(st)[1])          # ordinary points: Q6 does not bite
+    out["align_final"] = picp.align(scan, T_near)
+    diff = i64 != i32
+    print("G9 (Q6): neighbours that differ between the float64 and the float32 tree:", int(diff.sum()), "of", len(i64),
+          "(ordinary:", int(diff[:2000].sum()), ", near-tie queries:", int(diff[2000:].sum()), ")")
+    H, H32 = out["E_plane_H"], out["E_plane_H_f32tree"]
+    print("   max|dH|/max|H| between the two trees:", float(np.max(np.abs(H - H32)) / np.max(np.abs(H))))
     np.savez_compressed(os.path.join(HERE, "g9_q6_f64_target.npz"), **out)
 
 

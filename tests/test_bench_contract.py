@@ -45,5 +45,62 @@ def test_cpu_baseline_leg_runs_on_the_oracle():
     scan, _ = perturbed_scan(target, 5000, seed=2)
     out = bench.cpu_baseline("icp", target, scan, None, [np.eye(4)], 2.0, None, 1)
     assert out["kind"] == "port" and out["unit"] == "Mcorr/s" and out["value"] > 0 and out["cores"] >= 1
+    assert out["cores"] == out["effective_cpus"] == bench.effective_cpus()      # the OpenMP team = the CPU quota
     out = bench.cpu_baseline("ndt", target, scan, None, [np.eye(4)], 2.0, 1.0, 1)
     assert out["value"] > 0 and "sample" in out
+
+
+def test_self_launch_builds_the_torchrun_command(monkeypatch):
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run on 127.0.0.1."""
+    bench = _load_bench()
+    seen = {}
+
+    def fake_exec(file, argv, env):
+        seen.update(file=file, argv=list(argv), env=dict(env))
+        raise SystemExit(0)
+
+    monkeypatch.setattr(os, "execvpe", fake_exec)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    for k in ("WORLD_SIZE", "RANK"):
+        monkeypatch.delenv(k, raising=False)
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 0
+    a = seen["argv"]
+    assert a[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in a and "--nnodes=1" in a
+    assert a[a.index("--master-addr") + 1] == "127.0.0.1" and int(a[a.index("--master-port") + 1]) > 0
+    i = a.index(os.path.join(REPO, "bench.py"))
+    assert a[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_rank_environment_is_not_relaunched(monkeypatch):
+    """Under a launcher (RANK / WORLD_SIZE set) bench.py must NOT exec again; a world-size mismatch is an error."""
+    bench = _load_bench()
+    monkeypatch.setattr(os, "execvpe", lambda *a: (_ for _ in ()).throw(AssertionError("relaunched")))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    monkeypatch.setenv("WORLD_SIZE", "4"); monkeypatch.setenv("RANK", "0")
+    fd1 = os.dup(1)
+    try:
+        try:
+            bench.main()
+        except SystemExit as e:
+            assert "WORLD_SIZE=4" in str(e.code)
+        else:
+            raise AssertionError("expected SystemExit")
+    finally:
+        os.dup2(fd1, 1); os.close(fd1)
+
+
+def test_effective_cpus_respects_the_quota():
+    bench = _load_bench()
+    n = bench.effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            assert n <= max(int(float(q) / float(per)), 1)
+    except OSError:
+        pass

@@ -151,6 +151,86 @@ def _crop(points, lo, hi):
     return np.nonzero(np.all((points >= lo) & (points < hi), axis=1))[0]
 
 
+@pytest.mark.parametrize("kind_name,vs", [("vplane", 0.5), ("ndt", 1.0)])
+def test_10m_centroid_filter_is_pinned_at_config_size(capi, orc, street10m, kind_name, vs):
+    """the DEFAULT centroid search of BASELINE configs 2-3 (k_nn_filter: float32 filter search +
+    float64 check, k_nn_fix for what it cannot certify) pinned at the 10 M size the headline numbers are quoted on --
+    (a) the full 10 M-point pass, match by match and sum by sum, against the float64-only search (nn_mode 3) at a far
+        and a near pose;
+    (b) against the ORACLE: the oracle's own voxel build of the 10 M cloud (centroids bit-equal to the GPU's), three
+        boxes of the scan searched by brute force over cropped centroids (every query closer than the crop margin has
+        its global nearest centroid in the crop), sums of the cropped scan against the FULL voxel target through
+        k_nn_filter vs the oracle's reduce on the brute-force matches;
+    (c) the band the filter actually used at |coordinates| up to 600 m, restated from gn_math.h.
+    Reference: voxel.py:171-179 (KD-tree query over the float64 centroids), voxelized_plane_icp.py:37-43, ndt.py:32-37."""
+    kind = {"vplane": capi.VPLANE, "ndt": capi.NDT}[kind_name]
+    okind = {"vplane": orc.VPLANE, "ndt": orc.NDT}[kind_name]
+    ctx, target, scan = street10m["ctx"], street10m["target"], street10m["scan"]
+    md = 2.0
+    tgt = capi.Target.voxels(ctx, target, vs, 10)
+    sc = capi.Scan(ctx, scan)
+    T_near = np.eye(4); T_near[:3, 3] = [0.02, -0.01, 0.03]
+    poses = [np.eye(4), T_near, street10m["T_true"]]            # first pose of align(), a mid pose, the converged one
+    # ---- (a) filter vs float64-only, the whole 10 M scan
+    for T in poses:
+        got = {}
+        for name, mode in (("filter", 0), ("f64", 3)):
+            with ctx.pipeline(variant=1, fuse_finalize=1, nn_mode=mode, reuse=0):
+                out = capi.linearize(tgt, sc, kind, T, md).copy()
+                got[name] = (out, sc.matches())
+        assert np.array_equal(got["filter"][1], got["f64"][1])                 # every one of the 10 M matches
+        assert np.array_equal(got["filter"][0], got["f64"][0])                 # and therefore all 29 sums, bit for bit
+        assert got["filter"][0][28] == np.count_nonzero(got["filter"][1] >= 0) > 0.9 * scan.shape[0]
+        with ctx.pipeline(nn_mode=0):                                          # what ships (automatic reuse policy on)
+            assert np.array_equal(capi.linearize(tgt, sc, kind, T, md), got["f64"][0])
+    # ---- (c) the filter exists at this size and used the band gn_math.h prescribes for these coordinates
+    info = tgt.index_info()
+    assert info["halo_records"] > 0 and info["filter_band"] > 0
+    cell, dims = info["cell"], np.array(info["dims"], np.float64)
+    st = tgt.voxel_stats(("mean", "norm", "icov"))
+    lo = st["mean"].min(0)
+    maxabs_lo, maxabs_hi = np.abs(st["mean"]).max(), np.abs(np.concatenate([lo - cell, lo + (dims + 1) * cell])).max()
+    assert np.abs(target).max() > 590.0                                        # the tiled street does reach +-600 m
+    k_band = 1.7321 * 1.01 * 5.9604644775390625e-8
+    assert k_band * maxabs_lo <= info["filter_band"] <= k_band * maxabs_hi + 1e-12
+    assert info["filter_band"] <= 0.01 * cell
+    # rounding really moves no centroid by more than the band
+    moved = np.linalg.norm(st["mean"].astype(np.float32).astype(np.float64) - st["mean"], axis=1).max()
+    assert moved <= info["filter_band"]
+    # ---- (b) against the oracle
+    o = orc.voxel_build(target, vs, 10)
+    assert np.array_equal(o["mean"], st["mean"])                                # same voxels, same centroids, same order
+    icov6 = np.ascontiguousarray(st["icov"].reshape(-1, 9)[:, [0, 1, 2, 4, 5, 8]])
+    rec_b = st["norm"] if kind_name == "vplane" else icov6
+    margin = 2.5
+    lo_all, hi_all = target.min(0), target.max(0)
+    boxes = [(np.array([-15.0, -15.0, -1e9]), np.array([15.0, 15.0, 1e9])),
+             (np.array([hi_all[0] - 40, hi_all[1] - 40, -1e9]), np.array([hi_all[0] - 10, hi_all[1] - 10, 1e9])),
+             (np.array([lo_all[0] + 100, -20.0, -1e9]), np.array([lo_all[0] + 130, 10.0, 1e9]))]
+    rng = np.random.default_rng(11)
+    for T in (poses[0], poses[2]):
+        stf = orc.transform(T, scan)
+        for lo, hi in boxes:
+            ci = _crop(st["mean"], lo - margin, hi + margin)
+            qi = _crop(stf, lo, hi)
+            assert ci.size > 500 and qi.size > 1000
+            qi = np.sort(rng.choice(qi, min(6000, qi.size), replace=False))
+            crop = np.ascontiguousarray(st["mean"][ci])
+            src = np.ascontiguousarray(scan[qi])
+            do, io = orc.nn_brute_f64(crop, stf[qi])
+            sure = do < margin                              # (everything the 2 m gate lets through is "sure")
+            assert np.all(sure | (do >= md))
+            d, i = tgt.nn_query(stf[qi])                      # the float64 query kernel, unbounded
+            assert np.array_equal(i[sure], ci[io[sure]]) and np.array_equal(d[sure], do[sure])
+            with ctx.pipeline(variant=1, fuse_finalize=1, nn_mode=0, reuse=0):      # k_nn_filter on the cropped scan
+                out = capi.linearize(tgt, capi.Scan(ctx, src), kind, T, md)
+            Hg, gg, e2g, cntg = capi.unpack29(out)
+            Ho, go, e2o, cnto = orc.linearize(okind, T, src, stf[qi], crop, np.ascontiguousarray(rec_b[ci]), do, io, md)
+            assert cntg == cnto and cnto > 0.5 * qi.size
+            assert rel_H(Hg, Ho) < 1e-9 and abs(e2g - e2o) <= 1e-9 * abs(e2o)
+            assert np.max(np.abs(gg - go)) <= 1e-9 * np.max(np.abs(go))
+
+
 def test_100m_plane(capi, orc):
     """BASELINE config 4 size: 100 M-point target (251 M grid cells, 1.6 GB of records: nothing is
     cache-resident), 12.5 M-point scan shard, real k = 15 normals.  The oracle cannot hold 1e8 points, so

@@ -934,14 +934,33 @@ def test_certified_reuse_shared_point_target(capi, ctx):
 
 def test_quirk_q6_float64_target(capi, g9):
     """PlaneICP.set_target with a float64 target (quirk Q6, plane_icp.py:20-22): the class casts to float32 for the
-    search AND the gather; the reference searches the float64 array.  Same H / pose within the bars on the fixture."""
+    search AND the gather, the reference searches the float64 array.  On the fixture 82 of ~720 engineered near-ties get
+    another neighbour under the float64 tree and H moves by 2.5e-3 (tests/test_oracle_golden.py::
+    test_g9_quirk_q6_float64_target has the whole story); the HIP path must reproduce the reference's FLOAT32 tree:
+    neighbour for neighbour, H within 1e-5 of the reference class evaluated on that tree, the float64-tree reference
+    where no neighbour differs, the same pose."""
     import point_cloud_registration_amd as pcr
-    p = pcr.PlaneICP(max_dist=float(g9["max_dist"]), k=int(g9["k"]))
+    md = float(g9["max_dist"])
+    p = pcr.PlaneICP(max_dist=md, k=int(g9["k"]))
     p.set_target(g9["target"], "tree", g9["plane_normals"])
-    for tag, T in (("T", g9["T"]), ("I", np.eye(4))):
-        H, g, e2 = p.calc_H_g_e2(T, g9["source"])
-        assert rel_H(H, g9[f"{tag}_plane_H"]) < TOL_REF
-    assert _pose_close(p.align(g9["source"], np.eye(4)), g9["align_final"])
+    d, i = p.kdtree.query(g9["source_tie"])
+    assert np.array_equal(np.asarray(i), g9["nn_idx_f32_tree"])        # every query, the near-ties included
+    assert (g9["nn_idx_f64_tree"] != g9["nn_idx_f32_tree"]).sum() >= 50
+    I = np.eye(4)
+    for tag, T, sc in (("T", g9["T"], "source"), ("N", g9["T_near"], "source"), ("E", I, "source_tie")):
+        H, g, e2 = p.calc_H_g_e2(T, g9[sc])
+        assert rel_H(H, g9[f"{tag}_plane_H_f32tree"]) < TOL_REF, tag
+        assert abs(e2 - g9[f"{tag}_plane_e2_f32tree"]) < (5 * TOL_REF if tag == "E" else 2e-3) * abs(g9[f"{tag}_plane_e2_f32tree"])
+    H, g, e2 = p.calc_H_g_e2(g9["T"], g9["source"])
+    assert rel_H(H, g9["T_plane_H"]) < TOL_REF                         # float64-tree reference, Q6 not biting
+    H, g, e2 = p.calc_H_g_e2(I, g9["source_tie"])
+    assert 1e-4 < rel_H(H, g9["E_plane_H"]) < 1e-2                     # ... and biting: the documented deviation
+    # (compared where the data is: 500 m from the origin a rotation difference of 3e-7 rad moves the translation column
+    # by 1.5e-4 m although no scan point moves by more than a few 1e-5 m)
+    T_fin, ref = p.align(g9["source"], g9["T_near"]), g9["align_final"]
+    src = g9["source"].astype(np.float64)
+    moved = np.linalg.norm((src @ T_fin[:3, :3].T + T_fin[:3, 3]) - (src @ ref[:3, :3].T + ref[:3, 3]), axis=1)
+    assert moved.max() < 1e-4 and _pose_close(T_fin, ref, tol=5e-4)
 
 
 @pytest.mark.parametrize("offset", [0.0, 3.0e4, 2.0e7])

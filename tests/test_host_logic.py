@@ -196,6 +196,43 @@ def test_hash64_content_hash():
     assert dig(g) != dig(f)
 
 
+def test_hash64_survives_fork():
+    """after fork() the child inherits the hash pool without its threads; the next >= 1 MiB hash must not
+    wait for workers that do not exist.  (multiprocessing's default start method on Linux, DataLoader workers.)"""
+    import os
+    rng = np.random.default_rng(1)
+    a = rng.random((300_000, 3)).astype(np.float32)
+    h = _capi.hash64(a)                                            # the parent's pool exists now
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:                                                    # child
+        try:
+            os.close(r)
+            import signal
+            signal.alarm(30)                                        # a hang kills the child instead of the suite
+            v = _capi.hash64(a)
+            os.write(w, (b"ok" if v == h else b"bad"))
+        finally:
+            os._exit(0)
+    os.close(w)
+    got = os.read(r, 16)
+    os.close(r)
+    _, status = os.waitpid(pid, 0)
+    assert got == b"ok", (got, status)
+    assert _capi.hash64(a) == h                                     # and the parent's pool still works
+
+
+def test_usable_cpus_is_the_quota():
+    n = _capi.lib().pcr_usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1) if (os := __import__("os")) else True
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            assert n <= max(int(float(q) / float(per)), 1)
+    except OSError:
+        pass
+
+
 def test_reuse_policy_restated():
     """gn_choose_nn_mode / gn_typical_motion (csrc/gn_math.h) restated: the automatic policy never starts tracking on a
     quadratically converging run, keeps going once tracking, and the typical displacement is what it says."""
