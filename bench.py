@@ -65,6 +65,12 @@ CONFIGS = {
     "icp_b01_harness": ("icp", 1_060_000, 100_000, None,
                         "Point-to-Point ICP, B-01 stand-in, reference-harness scan: 100k random points shifted "
                         "by t=(0,0,0.3) + N(0,0.005) noise, init_T = I"),
+    # the reference's own benchmark for the voxel methods (benchmark/speed_test_comparison.py:36-55,166-170): map 1.06 M
+    # points, voxel_size 1, the harness' 100 k-point scan
+    "vplane_b01_harness": ("vplane", 1_060_000, 100_000, 1.0,
+                           "VPlaneICP voxel_size=1.0, B-01 stand-in, reference-harness scan (100k points, t=(0,0,0.3) + noise)"),
+    "ndt_b01_harness": ("ndt", 1_060_000, 100_000, 1.0,
+                        "NDT voxel_size=1.0, B-01 stand-in, reference-harness scan (100k points, t=(0,0,0.3) + noise)"),
     "vplane_10m": ("vplane", 10_000_000, 10_000_000, 0.5, "VPlaneICP voxel_size=0.5, synthetic 10M-pt cloud"),
     "ndt_10m": ("ndt", 10_000_000, 10_000_000, 1.0, "NDT voxel_size=1.0, synthetic 10M-pt cloud"),
     "plane_100m": ("plane", 100_000_000, 12_500_000, None,

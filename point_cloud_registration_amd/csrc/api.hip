@@ -187,6 +187,10 @@ extern "C" pcr_status pcr_context_create(int device, pcr_context **out) {
     if (cm && atof(cm) > 0) ctx->voxel_cell_mult = atof(cm);
     const char *vf = getenv("PCR_VOX_FILTER");
     if (vf && *vf) ctx->vox_filter = atoi(vf) != 0;
+    const char *fa = getenv("PCR_FILTER_AFTER");
+    if (fa && *fa) ctx->filter_after = atoi(fa);
+    const char *fs = getenv("PCR_FILTER_SETTLE");
+    if (fs && *fs) ctx->filter_settle = atoi(fs) != 0;
     const char *vo = getenv("PCR_VOX_OCC");
     if (vo && *vo) ctx->vox_occ = atoi(vo) != 0;
     const char *tl = getenv("PCR_TILE_LOCAL");

@@ -458,7 +458,7 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
     if (sizeof(Real) == 4 && halo_frac > 0 && n > 0 && g.cs_mask != 0xffffffffu) {
         Geom<float> gh;
         memcpy(&gh, &g, sizeof gh);                           // Real == float here
-        gh.halo = (float)(fmin(halo_frac, 0.45) * (double)g.h);
+        gh.halo = (float)(fmin(halo_frac, 1.0) * (double)g.h);     // (1.0: a cell's list = all points of its 27-cell block)
         const size_t nc1 = (size_t)ncells + 1;
         HIP_TRY(d_cs_h.alloc_exact(nc1));
         HIP_TRY(hipMemsetAsync(d_cs_h.p, 0, sizeof(uint32_t) * nc1, ctx->stream));

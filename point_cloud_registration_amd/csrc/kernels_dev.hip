@@ -11,7 +11,7 @@ __global__ void __launch_bounds__(256) k_linearize(const LinArgs a) {
     double acc[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-    linearize_body<KIND, HALO>(a, P, acc);
+    linearize_body<KIND, HALO, 0>(a, P, acc);
     block_store_partials(acc, a.partials);
 }
 

@@ -63,17 +63,23 @@ struct NNTrack {
     Real prune;       // current pruning bound (>= best)
     Real pmin;        // smallest pruning bound used so far
     Real two_mu, mu2; // 2 mu, mu^2
+    // TRACK == 2 (the float32 filter of the centroid search settles two-way near-ties itself): the runner-up's identity,
+    // and `third` = min squared distance over examined candidates other than the winner AND the runner-up; the search
+    // then prunes with min(third, (sqrt(best) + mu)^2), so that min(third, pmin) bounds everybody but those two
+    Real third;
+    uint32_t sec_o;
 };
 
 template <typename Real>
 __device__ __forceinline__ void nn_track_init(NNTrack<Real> &tk, Real bound2, Real mu) {
     tk.second = bound2; tk.prune = bound2; tk.pmin = bound2; tk.two_mu = mu + mu; tk.mu2 = mu * mu;
+    tk.third = bound2; tk.sec_o = 0xffffffffu;
 }
 
 // The search tracks (squared distance, original index) -- the oracle's tie rule -- and, for the reduce
 // kernel's gather, the index `j` of the winner in the array it was read from (the cell-sorted array, or
 // an extended list whose entries are translated through Geom::j_h right after ring 0).
-template <typename Real, typename PT, bool TRACK = false>
+template <typename Real, typename PT, int TRACK = 0>
 __device__ __forceinline__ void nn_test(const PT &p, uint32_t j, Real qx, Real qy, Real qz,
                                         Real &best, uint32_t &bj, uint32_t &borig, NNTrack<Real> *tk = nullptr) {
     const Real dx = qx - (Real)p.x, dy = qy - (Real)p.y, dz = qz - (Real)p.z;
@@ -94,7 +100,7 @@ __device__ __forceinline__ void nn_test(const PT &p, uint32_t j, Real qx, Real q
 // float32 specialisation: d >= 0, so the bit patterns of squared distances order like the values and
 // (distance, original index) packs into ONE unsigned 64-bit key -- "closer, ties to the smaller
 // index" becomes a single 64-bit compare instead of three compares and two mask operations.
-template <bool TRACK>
+template <int TRACK>
 __device__ __forceinline__ void nn_test_f32(const float4 &p, uint32_t j, float qx, float qy, float qz,
                                             float &best, uint32_t &bj, uint32_t &borig, NNTrack<float> *tk) {
     const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
@@ -103,32 +109,49 @@ __device__ __forceinline__ void nn_test_f32(const float4 &p, uint32_t j, float q
     const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | o;
     const unsigned long long cur = ((unsigned long long)__float_as_uint(best) << 32) | borig;
     const bool take = key < cur;
-    if (TRACK) {
+    if (TRACK == 1) {
         const bool same = key == cur;
         const float other = take ? best : d;
         tk->second = same ? tk->second : fminf(tk->second, other);
     }
+    if (TRACK == 2) {
+        // the loser of the comparison, unless the candidate is the current winner or the current runner-up seen again
+        // (halo copies are revisited by ring 1, batches over-read into the next cell): those change nothing
+        const unsigned long long sec = ((unsigned long long)__float_as_uint(tk->second) << 32) | tk->sec_o;
+        const bool again = (key == cur) | (key == sec);
+        const float other = again ? __int_as_float(0x7f800000) : (take ? best : d);
+        const uint32_t other_o = take ? borig : o;
+        const bool closer = other < tk->second;                        // (strict: an equal later one goes to `third`)
+        tk->third = fminf(tk->third, fmaxf(tk->second, other));        // whoever drops out of the first two
+        tk->sec_o = closer ? other_o : tk->sec_o;
+        tk->second = fminf(tk->second, other);
+    }
     best = take ? d : best; bj = take ? j : bj; borig = take ? o : borig;
 }
 template <>
-__device__ __forceinline__ void nn_test<float, float4, false>(const float4 &p, uint32_t j, float qx, float qy, float qz,
+__device__ __forceinline__ void nn_test<float, float4, 0>(const float4 &p, uint32_t j, float qx, float qy, float qz,
                                                               float &best, uint32_t &bj, uint32_t &borig, NNTrack<float> *tk) {
-    nn_test_f32<false>(p, j, qx, qy, qz, best, bj, borig, tk);
+    nn_test_f32<0>(p, j, qx, qy, qz, best, bj, borig, tk);
 }
 template <>
-__device__ __forceinline__ void nn_test<float, float4, true>(const float4 &p, uint32_t j, float qx, float qy, float qz,
-                                                             float &best, uint32_t &bj, uint32_t &borig, NNTrack<float> *tk) {
-    nn_test_f32<true>(p, j, qx, qy, qz, best, bj, borig, tk);
+__device__ __forceinline__ void nn_test<float, float4, 1>(const float4 &p, uint32_t j, float qx, float qy, float qz,
+                                                          float &best, uint32_t &bj, uint32_t &borig, NNTrack<float> *tk) {
+    nn_test_f32<1>(p, j, qx, qy, qz, best, bj, borig, tk);
+}
+template <>
+__device__ __forceinline__ void nn_test<float, float4, 2>(const float4 &p, uint32_t j, float qx, float qy, float qz,
+                                                          float &best, uint32_t &bj, uint32_t &borig, NNTrack<float> *tk) {
+    nn_test_f32<2>(p, j, qx, qy, qz, best, bj, borig, tk);
 }
 
 // refresh the pruning bound of a tracking search after `best` / `second` may have changed
-template <typename Real>
+template <typename Real, int TRACK = 1>
 __device__ __forceinline__ void nn_track_refresh(NNTrack<Real> &tk, Real best) {
     typedef RealTraits<Real> RT;
     // (sqrt(best) + mu)^2; any value >= best is a valid bound, so the fast sqrt is fine: what is recorded in
     // pmin is the value that was actually used
     const Real infl = best + (tk.two_mu * RT::sqrt_fast(best) + tk.mu2);
-    const Real p = fmin(tk.second, infl);
+    const Real p = fmin(TRACK == 2 ? tk.third : tk.second, infl);
     tk.prune = p;
     tk.pmin = fmin(tk.pmin, p);
 }
@@ -145,7 +168,7 @@ __device__ __forceinline__ void nn_track_refresh(NNTrack<Real> &tk, Real best) {
 #ifndef PCR_NN_BATCH_SMALL   // PCR_NN_BATCH_SMALL (100 k-point ICP harness scan 42.3 -> 38.4 us per pass with 8)
 #define PCR_NN_BATCH_SMALL 8
 #endif
-template <typename Real, typename PT, bool TRACK = false, int B = PCR_NN_BATCH>
+template <typename Real, typename PT, int TRACK = 0, int B = PCR_NN_BATCH>
 __device__ __forceinline__ void nn_scan_range(const PT *__restrict__ pts, uint32_t s, uint32_t e,
                                               Real qx, Real qy, Real qz, Real &best, uint32_t &bj, uint32_t &borig,
                                               NNTrack<Real> *tk = nullptr) {
@@ -157,7 +180,7 @@ __device__ __forceinline__ void nn_scan_range(const PT *__restrict__ pts, uint32
 #pragma unroll
         for (int u = 0; u < B; ++u) nn_test<Real, PT, TRACK>(p[u], j + u, qx, qy, qz, best, bj, borig, tk);
     }
-    if (TRACK) nn_track_refresh<Real>(*tk, best);
+    if (TRACK) nn_track_refresh<Real, TRACK>(*tk, best);
 }
 
 // Per-lane work counters, compiled in only for pcr_nn_counters (STATS = true).
@@ -203,7 +226,7 @@ __device__ __forceinline__ NNCell<Real> nn_cell(const Geom<Real> &g, Real qx, Re
 // nearly converged query (residual << halo) is certified by ring 0 alone and never enters the ring
 // loop: without the halo the ~8 % of lanes that sit closer to a face than to their match drag their
 // whole wave through ring 1 (measured: 75 % of the wave time at the converged pose).
-template <typename Real, typename PT, bool STATS = false, bool HALO = false, bool TRACK = false, int B = PCR_NN_BATCH>
+template <typename Real, typename PT, bool STATS = false, bool HALO = false, int TRACK = 0, int B = PCR_NN_BATCH>
 __device__ __forceinline__ int nn_ring0(const Geom<Real> &g, const PT *__restrict__ pts, const uint32_t *__restrict__ cs,
                                         NNCell<Real> &c, Real qx, Real qy, Real qz,
                                         Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr,
@@ -214,26 +237,33 @@ __device__ __forceinline__ int nn_ring0(const Geom<Real> &g, const PT *__restric
     const uint32_t *__restrict__ csr = ext ? g.cs_h : cs;
     const uint32_t w0 = csr[own], w1 = csr[own + 1];
     const int gap = g.cs_mask != 0xffffffffu ? (int)(w0 >> PCR_GAP_SHIFT) : 0;
-    if (gap == 0) {
+    if (ext) {
+        // the extended list holds COPIES: track the position in it, then translate the winner to its
+        // cell-sorted index (j_h is laid out like the lists, so neighbouring queries share its lines).
+        // An EMPTY cell may have a list too (its neighbours' points within the halo): a far-pose query that
+        // landed one cell off the surface is served like one inside an occupied cell.
         const uint32_t s_ = w0 & g.cs_mask, e_ = w1 & g.cs_mask;
-        if (STATS) { st->rings++; st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-        if (ext) {
-            // the extended list holds COPIES: track the position in it, then translate the winner to its
-            // cell-sorted index (j_h is laid out like the lists, so neighbouring queries share its lines)
+        if (e_ > s_) {
+            if (STATS) { st->rings++; st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
             uint32_t ej = PCR_NONE;
             nn_scan_range<Real, PT, TRACK, B>((const PT *)g.pts_h, s_, e_, qx, qy, qz, best, ej, borig, tk);
             if (ej != PCR_NONE) bj = g.j_h[ej];
             c.reach0 = g.halo;
-        } else {
-            nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
+            // a whole-cell halo: the list held every point of rings 0 and 1; rings closer than the gap are empty anyway
+            const int base = g.halo >= g.h ? 2 : 1;
+            return gap > base ? gap : base;
         }
+    } else if (gap == 0) {
+        const uint32_t s_ = w0 & g.cs_mask, e_ = w1 & g.cs_mask;
+        if (STATS) { st->rings++; st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
+        nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
         return 1;
     }
     if (g.seed) {                                 // a real point nearby bounds the search from the start
         const uint32_t j0 = g.seed[own];
         if (j0 != PCR_NONE) {
             nn_test<Real, PT, TRACK>(pts[j0], j0, qx, qy, qz, best, bj, borig, tk);
-            if (TRACK) nn_track_refresh<Real>(*tk, best);
+            if (TRACK) nn_track_refresh<Real, TRACK>(*tk, best);
         }
     }
     return gap;                                   // rings closer than `gap` are empty
@@ -253,7 +283,7 @@ __device__ __forceinline__ bool nn_certified(const Geom<Real> &g, const NNCell<R
 
 // Rings kstart (>= 1) .. kmax.
 // (a tracking search prunes with tk->prune wherever the plain one prunes with best: PB below)
-template <typename Real, typename PT, bool STATS = false, bool TRACK = false, int B = PCR_NN_BATCH>
+template <typename Real, typename PT, bool STATS = false, int TRACK = 0, int B = PCR_NN_BATCH>
 __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restrict__ pts, const uint32_t *__restrict__ cs,
                                          const NNCell<Real> &c, int kstart, Real qx, Real qy, Real qz,
                                          Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr,
@@ -323,7 +353,7 @@ __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restri
 // The same rings with the rows of a slab taken from the row-occupancy bitmap (Geom::rowocc): the centroid search when
 // the gate spans >= 5 rings (kernels.hip: k_nn_scan<VOXEL = 2>).  A separate function on purpose: routing the plain
 // search through the shared row body (a lambda) cost the 1e8-point search 5-13 % (74.5 / 80.5 vs 70.9 ms per 26 passes).
-template <typename Real, typename PT, bool STATS = false, bool TRACK = false>
+template <typename Real, typename PT, bool STATS = false, int TRACK = 0>
 __device__ __forceinline__ void nn_rings_occ(const Geom<Real> &g, const PT *__restrict__ pts, const uint32_t *__restrict__ cs,
                                          const NNCell<Real> &c, int kstart, Real qx, Real qy, Real qz,
                                          Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr,
@@ -423,7 +453,7 @@ __device__ __forceinline__ void nn_rings_occ(const Geom<Real> &g, const PT *__re
 // the search then only has to look inside that radius) or (bound2, PCR_NONE, PCR_NONE).
 // TRACK: `tk` was initialised with nn_track_init(tk, bound2, mu); on return min(tk->second, tk->pmin) is a lower
 // bound on the squared distance to every target point other than the winner (to every point if there is none).
-template <typename Real, typename PT, bool STATS = false, bool SEEDED = false, bool HALO = false, bool TRACK = false, bool OCC = false,
+template <typename Real, typename PT, bool STATS = false, bool SEEDED = false, bool HALO = false, int TRACK = 0, bool OCC = false,
           int B = PCR_NN_BATCH>
 __device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restrict__ pts,
                                           const uint32_t *__restrict__ cs,

@@ -358,7 +358,10 @@ struct TileIter {
 // for small ones, where a pass is a chain of dependent cold misses rather than a throughput problem: one
 // launch less, no round trip of the matches through HBM (100 k-point scan: 48.8 vs 58.9 us per pass).
 // The host picks per launch (pcr_set_variant: 2 = automatic, the default).
-template <int KIND, int HALO>
+// FILT (voxel kinds, round 4): the centroid search runs the float32 filter search with two-way settling (nn_filter_core)
+// and falls back to the float64 search inline for what that cannot certify (a third centroid inside the margin: rare
+// enough that the extra chain does not show); HALO then says whether the FILTER index has the extended lists.
+template <int KIND, int HALO, int FILT>
 __device__ __forceinline__ void linearize_body(const LinArgs &a, const PoseK &P, double *acc) {
     const TileIter it(a);
     for (int64_t i = it.base; i < it.end; i += it.stride) {
@@ -372,6 +375,14 @@ __device__ __forceinline__ void linearize_body(const LinArgs &a, const PoseK &P,
             nn_search<float, PtF, false, false, HALO != 0, false, false, PCR_NN_BATCH_SMALL>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f,
                                                                                           best, bj, bo);
             ok = bj != PCR_NONE && __builtin_sqrtf(best) < a.md_f;                 // icp.py:34 strict gate
+        } else if (FILT) {
+            double d;
+            bool cert = nn_filter_core<HALO, 1, PCR_NN_BATCH_SMALL>(a, tx, ty, tz, bj, d);
+            if (!cert) {
+                nn_search<double, PtD, false, false, false, false, false, PCR_NN_BATCH_SMALL>(a.gd, a.means, a.cell_start, (double)tx, (double)ty,
+                                                                                           (double)tz, a.bound2_d, d, bj, bo);
+            }
+            ok = bj != PCR_NONE && __builtin_sqrt(d) < a.md_d;                    // voxelized_plane_icp.py:38
         } else {
             double best;
             nn_search<double, PtD, false, false, false, false, false, PCR_NN_BATCH_SMALL>(a.gd, a.means, a.cell_start, (double)tx, (double)ty,
@@ -548,28 +559,52 @@ __device__ __forceinline__ void nn_point(const LinArgs &a, const PoseK &P, const
 // k_nn_fix returns at once when no lane asked (it runs the float64 search for the pending points: identical results by
 // construction, `test_centroid_filter_is_exact`).  Inlining that search here instead cost 96 VGPRs + 140 spilled SGPRs.
 #define PCR_PENDING 0xfffffffeu
-template <int HALO>
-__device__ __forceinline__ void nn_point_filter(const LinArgs &a, const PoseK &P, int64_t i) {
-    const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
-    float tx, ty, tz;
-    xform(P, x, y, z, tx, ty, tz);
+// SETTLE (round 4): the tracking search also carries the RUNNER-UP's index and a bound on everybody but the first two
+// (NNTrack::third, nn_test_f32<2>).  A lane whose winner cannot be certified alone -- two rounded centroids within the
+// margin of the same distance -- computes the runner-up's float64 distance too, takes the nearer of the two by the float64
+// search's own rule (distance, then the smaller ORIGINAL index), and certifies THAT against the third bound.  Only a
+// third candidate inside the margin is left pending.
+// (the search + check for one transformed point: returns true when the answer is CERTIFIED -- w = cell-sorted index of the
+// nearest centroid or PCR_NONE when nothing lies within the search bound, d = its squared float64 distance)
+template <int HALO, int SETTLE, int B = PCR_NN_BATCH>
+__device__ __forceinline__ bool nn_filter_core(const LinArgs &a, float tx, float ty, float tz, uint32_t &w, double &d) {
     uint32_t fj = PCR_NONE, fo = PCR_NONE;
     float best = a.bound2_ff;
     NNTrack<float> tk;
     nn_track_init<float>(tk, a.bound2_ff, a.mu_ff);
-    nn_search<float, PtF, false, false, HALO != 0, true>(a.gf, a.pts, a.cs_f, tx, ty, tz, a.bound2_ff, best, fj, fo, nullptr, &tk);
-    uint32_t out = PCR_NONE;       // nothing within bound + band among the rounded centroids: nothing within the gate
-    if (fo != PCR_NONE) {
-        const PtD m = a.means[fo];
-        const double dx = (double)tx - m.x, dy = (double)ty - m.y, dz = (double)tz - m.z;
-        const double d = (dx * dx + dy * dy) + dz * dz;
-        const float lbq = __builtin_sqrtf(fminf(tk.second, tk.pmin)) * 0.99999f - a.band_f;
-        const bool cert = lbq > 0.f && (double)lbq * (double)lbq > d * 1.000001;
-        out = __builtin_sqrt(d) < a.md_d ? fo : PCR_NONE;
-        if (!cert) {
-            out = PCR_PENDING;
-            atomicMax(a.pending, a.stamp);
-        }
+    nn_search<float, PtF, false, false, HALO != 0, SETTLE ? 2 : 1, false, B>(a.gf, a.pts, a.cs_f, tx, ty, tz, a.bound2_ff, best, fj, fo, nullptr, &tk);
+    w = PCR_NONE; d = 0.0;         // nothing within bound + band among the rounded centroids: nothing within the gate
+    if (fo == PCR_NONE) return true;
+    const PtD m = a.means[fo];
+    const double dx = (double)tx - m.x, dy = (double)ty - m.y, dz = (double)tz - m.z;
+    d = (dx * dx + dy * dy) + dz * dz;
+    const float lbq = __builtin_sqrtf(fminf(tk.second, tk.pmin)) * 0.99999f - a.band_f;
+    bool cert = lbq > 0.f && (double)lbq * (double)lbq > d * 1.000001;
+    w = fo;
+    if (SETTLE && !cert && tk.sec_o != PCR_NONE) {
+        const PtD m2 = a.means[tk.sec_o];
+        const double ex = (double)tx - m2.x, ey = (double)ty - m2.y, ez = (double)tz - m2.z;
+        const double d2 = (ex * ex + ey * ey) + ez * ez;
+        const bool take2 = (d2 < d) | ((d2 == d) & (pt_orig(m2) < pt_orig(m)));     // nn_test<double>'s rule
+        w = take2 ? tk.sec_o : fo;
+        d = take2 ? d2 : d;
+        const float lb3 = __builtin_sqrtf(fminf(tk.third, tk.pmin)) * 0.99999f - a.band_f;
+        cert = lb3 > 0.f && (double)lb3 * (double)lb3 > d * 1.000001;
+    }
+    return cert;
+}
+
+template <int HALO, int SETTLE>
+__device__ __forceinline__ void nn_point_filter(const LinArgs &a, const PoseK &P, int64_t i) {
+    const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
+    float tx, ty, tz;
+    xform(P, x, y, z, tx, ty, tz);
+    uint32_t w; double d;
+    const bool cert = nn_filter_core<HALO, SETTLE>(a, tx, ty, tz, w, d);
+    uint32_t out = (w != PCR_NONE && __builtin_sqrt(d) < a.md_d) ? w : PCR_NONE;
+    if (!cert) {
+        out = PCR_PENDING;
+        atomicMax(a.pending, a.stamp);
     }
     a.nn_j[i] = out;
 }

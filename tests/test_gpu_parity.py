@@ -621,7 +621,7 @@ def test_class_level_helpers(capi, orc, g2, g6, capsys):
     assert out[0].startswith("iter 0, error ") and len(out) == icp.last_iterations
 
 
-@pytest.fixture(params=["0", "0.05", "0.1", "0.3", "0.45"])
+@pytest.fixture(params=["0", "0.05", "0.1", "0.3", "0.45", "0.7", "1.0"])
 def halo(request, monkeypatch):
     """PCR_HALO (margin of the extended per-cell lists as a fraction of the cell edge; 0.1 ships, 0 = none):
     read when a point target is built."""
