@@ -100,6 +100,9 @@ def parse():
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps passes; the median is reported")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--event-period", type=int, default=3, help="HIP events around every n-th pass")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the two live rocprofv3 --pmc passes behind roofline.traffic (also: PCR_BENCH_NO_PMC=1)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)     # the short run rocprofv3 wraps
     ap.add_argument("--backend", default=os.environ.get("PCR_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="torch.distributed backend of the N > 1 plumbing (barrier, max over ranks); nccl = RCCL")
     return ap.parse_args()
@@ -125,6 +128,66 @@ def effective_cpus():
     if quota is not None:
         n = min(n, max(int(quota), 1))
     return max(n, 1)
+
+
+HOT_KERNELS = ("k_nn_scan", "k_nn_filter", "k_nn_fix", "k_nn_coop", "k_certify", "k_reduce_finalize", "k_linearize_finalize",
+               "k_reduce<", "k_linearize<", "k_finalize")
+
+
+def live_traffic(args):
+    """roofline.traffic measured by THIS run: the same workload is re-executed twice as a short child process under
+    ``rocprofv3 --kernel-trace --pmc FETCH_SIZE`` and ``... --pmc WRITE_SIZE`` (separate passes, as MI355X_MICROARCH.md
+    prescribes for the TCC counters; nothing else is traced), the rocpd database is read back and the bytes of the
+    hot-path kernels are averaged per pass (= per launch of the kernel that folds).  Corrections of the guide: the
+    counters are in KB, FETCH_SIZE reads half of the true bytes on gfx950.  Fabric-side bytes: Infinity-Cache hits are
+    counted, so this is an upper bound on HBM traffic.  Returns (bytes_per_pass, source) or (None, {"error": ...})."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, {"error": "rocprofv3 not found"}
+    child = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--steps", "10", "--warmup", "2", "--repeats", "1",
+             "--no-cpu-baseline", "--no-pmc", "--pmc-child"]
+    if args.variant is not None:
+        child += ["--variant", str(args.variant)]
+    env = dict(os.environ, TMPDIR="/tmp", PCR_BENCH_NO_RCCL_PROBE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    by, passes, errs = {}, None, []
+    for counter, scale in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):
+        out = tempfile.mkdtemp(prefix="pcr_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "rocpd", "-d", out, "-o", "r", "--"] + child,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                errs.append(f"{counter}: rc {r.returncode} {r.stderr[-200:]}")
+                continue
+            cur = sqlite3.connect(dbs[0]).cursor()
+            rows = cur.execute("select name, count(*), sum(counter_value) from pmc_events where counter_name = ? group by name",
+                               (counter,)).fetchall()
+            for name, n, total in rows:
+                if not any(h in name for h in HOT_KERNELS):
+                    continue
+                k = name.replace("void ", "").split("(")[0].strip()
+                e = by.setdefault(k, {"launches": int(n), "fetch_bytes": 0, "write_bytes": 0})
+                e["fetch_bytes" if counter == "FETCH_SIZE" else "write_bytes"] = int(round(total * scale / max(n, 1)))
+        except Exception as exc:                              # noqa: BLE001 -- a probe must not take the bench line down
+            errs.append(f"{counter}: {type(exc).__name__}: {exc}"[:200])
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    if not by or errs:
+        return None, {"error": "; ".join(errs) or "no hot-path kernels in the PMC output"}
+    passes = max([v["launches"] for k, v in by.items() if "finalize" in k] or [0])
+    if passes <= 0:
+        return None, {"error": "no folding kernel in the PMC output"}
+    total = sum((v["fetch_bytes"] + v["write_bytes"]) * v["launches"] for v in by.values()) / passes
+    return int(round(total)), {"live": True, "tool": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes)",
+                               "passes": passes, "corrections": "KB -> bytes; FETCH_SIZE x2 (gfx950)",
+                               "by_kernel_bytes_per_launch": by}
 
 
 def self_launch(args):
@@ -356,7 +419,10 @@ def main():
         # profile was taken on these very kernels (hash of the HIP sources), otherwise null
         traffic, traffic_src = None, None
         pmc_file = os.path.join(REPO, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc_file):
+        if world == 1 and not args.no_pmc and not args.pmc_child and not os.environ.get("PCR_BENCH_NO_PMC"):
+            traffic, traffic_src = live_traffic(args)
+        if traffic is None and os.path.exists(pmc_file):
+            live_err = traffic_src
             try:
                 pm = json.load(open(pmc_file))
                 entry = pm.get(args.config, {})
@@ -369,6 +435,8 @@ def main():
                                    "note": "PMC profile predates the current kernels; traffic withheld"}
             except Exception:
                 traffic = None
+            if live_err and isinstance(traffic_src, dict):
+                traffic_src["live_attempt"] = live_err
         line = {
             "metric": "M-correspondences/sec, %s calc_H_g_e2 on the B-01 stand-in (1.06 M pts)" % kind_name
                       if "b01" in args.config else "M-correspondences/sec, %s calc_H_g_e2" % kind_name,
@@ -409,9 +477,9 @@ def main():
                                               "kernel_ms": round(kern["reduce"]["avg_ms"], 5)}
         if per_rank is not None:
             line["per_rank_kernel_ms"] = per_rank
-        if world == 1 and not use_comm and not os.environ.get("PCR_BENCH_NO_RCCL_PROBE"):
+        if world == 1 and not use_comm and not os.environ.get("PCR_BENCH_NO_RCCL_PROBE") and not args.pmc_child:
             line["rccl_1rank"] = rccl_one_rank_probe(ctx, step, args.steps, sync_all)
-        if world == 1:
+        if world == 1 and not args.pmc_child:
             line["seam"] = seam_timings(kind_name, target, scan, tgt, sc, kind, traj, max_dist, voxel_size, n_target)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(kind_name, target, scan, tgt, traj, max_dist, voxel_size,

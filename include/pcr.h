@@ -255,6 +255,10 @@ PCR_API pcr_status pcr_scan_reuse_stats(pcr_scan *s, double out[8]);
 /* variant 1: 1 (default) = the reduce kernel folds the per-block partial sums itself
  * (k_reduce_finalize); 0 = separate fold kernel                                             */
 PCR_API pcr_status pcr_set_fuse_finalize(pcr_context *ctx, int on);
+/* 1 when the library carries the developer / A-B kernels (unfused folds, the wave-cooperative LDS-staged search, the work
+ * counters: csrc/kernels_dev.hip) -- libpcr_hip_dev.so, built by `make DEV=1`; the shipped libpcr_hip.so returns 0 and
+ * refuses pcr_set_nn_mode(2), pcr_set_fuse_finalize(0) and pcr_nn_counters with PCR_ERR_INVALID.                      */
+PCR_API int pcr_has_dev_kernels(void);
 PCR_API pcr_status pcr_get_pipeline(pcr_context *ctx, int *variant, int *fuse_finalize, int *nn_mode);
 
 #ifdef __cplusplus

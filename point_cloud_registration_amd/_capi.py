@@ -12,8 +12,10 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# PCR_LIB: developer switch, an experimental build of the same library (tools/build_variant.sh)
+# PCR_LIB: developer switch, another build of the same library: libpcr_hip_dev.so (`make dev`: + the developer / A-B
+# kernels of csrc/kernels_dev.hip), or an experimental variant (tools/build_variant.sh)
 LIB_PATH = os.environ.get("PCR_LIB") or os.path.join(_HERE, "libpcr_hip.so")
+DEV_LIB_PATH = os.path.join(_HERE, "libpcr_hip_dev.so")
 
 PCR_OK = 0
 PCR_ERR_INVALID, PCR_ERR_HIP, PCR_ERR_NO_TARGET, PCR_ERR_COMM, PCR_ERR_SINGULAR, PCR_ERR_NOMEM = -1, -2, -3, -4, -5, -6
@@ -86,6 +88,7 @@ PROTOTYPES = {
     "pcr_hash64": (C.c_int, [_vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "pcr_target_filter_band": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "pcr_usable_cpus": (C.c_int, []),
+    "pcr_has_dev_kernels": (C.c_int, []),
     "pcr_abi_version": (C.c_int, []),
     "pcr_context_trim": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "pcr_profile_read_n": (C.c_int, [_vp, C.c_int, _i64p, _f64p, C.POINTER(C.c_int)]),
@@ -176,6 +179,11 @@ def check(status):
     if status == PCR_ERR_NO_TARGET:
         raise ValueError(msg)
     raise PcrError(f"libpcr_hip status {status}: {msg}")
+
+
+def has_dev_kernels():
+    """True when the loaded library is a developer build (unfused folds, wave-cooperative search, work counters)."""
+    return bool(lib().pcr_has_dev_kernels())
 
 
 def device_count():

@@ -176,11 +176,17 @@ extern "C" pcr_status pcr_context_create(int device, pcr_context **out) {
     if (nm && *nm) {
         // the values pcr_set_nn_mode accepts; anything else (1 was a search variant of round 2) -> the shipped search
         const int m = atoi(nm);
+#ifdef PCR_DEV
         if (m == 0 || m == 2 || m == 3) ctx->nn_mode = m;
+#else
+        if (m == 0 || m == 3) ctx->nn_mode = m;
+#endif
         else fprintf(stderr, "[pcr] PCR_NN_MODE=%s is not a search mode of this library (0, 2, 3): using 0\n", nm);
     }
+#ifdef PCR_DEV
     const char *ff = getenv("PCR_FUSE_FINALIZE");
     if (ff && *ff) ctx->fuse_finalize = atoi(ff) != 0;
+#endif
     const char *lf = getenv("PCR_LOCAL_FRAC");
     if (lf && *lf) ctx->local_frac = atof(lf);
     const char *cm = getenv("PCR_VOXEL_CELL_MULT");
@@ -189,8 +195,6 @@ extern "C" pcr_status pcr_context_create(int device, pcr_context **out) {
     if (vf && *vf) ctx->vox_filter = atoi(vf) != 0;
     const char *fa = getenv("PCR_FILTER_AFTER");
     if (fa && *fa) ctx->filter_after = atoi(fa);
-    const char *fs = getenv("PCR_FILTER_SETTLE");
-    if (fs && *fs) ctx->filter_settle = atoi(fs) != 0;
     const char *vo = getenv("PCR_VOX_OCC");
     if (vo && *vo) ctx->vox_occ = atoi(vo) != 0;
     const char *tl = getenv("PCR_TILE_LOCAL");
@@ -267,8 +271,26 @@ extern "C" pcr_status pcr_get_variant(pcr_context *ctx, int *variant) {
     return PCR_OK;
 }
 
+// ---- developer kernels (kernels_dev.hip): only in a library built with `make DEV=1` (libpcr_hip_dev.so) ----
+extern "C" int pcr_has_dev_kernels(void) {
+#ifdef PCR_DEV
+    return 1;
+#else
+    return 0;
+#endif
+}
+#ifndef PCR_DEV
+extern "C" pcr_status pcr_nn_counters(pcr_target *, pcr_scan *, const double *, double, double *) {
+    pcr_set_error("pcr_nn_counters needs the developer build of the library (make DEV=1: libpcr_hip_dev.so)");
+    return PCR_ERR_INVALID;
+}
+#endif
+
 extern "C" pcr_status pcr_set_fuse_finalize(pcr_context *ctx, int on) {
     PCR_REQUIRE(ctx, "ctx is NULL");
+#ifndef PCR_DEV
+    PCR_REQUIRE(on != 0, "the unfused fold kernels are in the developer build only (make DEV=1: libpcr_hip_dev.so)");
+#endif
     ctx->fuse_finalize = on != 0;
     return PCR_OK;
 }
@@ -284,6 +306,9 @@ extern "C" pcr_status pcr_get_pipeline(pcr_context *ctx, int *variant, int *fuse
 extern "C" pcr_status pcr_set_nn_mode(pcr_context *ctx, int mode) {
     PCR_REQUIRE(ctx, "ctx is NULL");
     PCR_REQUIRE(mode == 0 || mode == 2 || mode == 3, "nn mode must be 0, 2 or 3");
+#ifndef PCR_DEV
+    PCR_REQUIRE(mode != 2, "the wave-cooperative search is in the developer build only (make DEV=1: libpcr_hip_dev.so)");
+#endif
     ctx->nn_mode = mode;
     return PCR_OK;
 }

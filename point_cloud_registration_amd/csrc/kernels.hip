@@ -190,28 +190,36 @@ __global__ void __launch_bounds__(256, VOXEL == 2 ? PCR_VOX_WAVES : 5) k_nn_scan
 }
 
 // Plain pass over a voxel target that has a float32 filter index (pass_device.h: nn_point_filter)
-template <int HALO, int LOCAL, int SETTLE>
+// (Two-way settling inside this kernel -- nn_point_filter<HALO, 1>: the search also tracks the runner-up and a third bound,
+// +8 VALU operations per candidate -- was measured on both 10 M configs in round 4: search 570 -> 640 us and 380 -> 429 us per
+// pass, more than the pending points cost anywhere.  The fused small-scan kernel, where one extra search chain doubles the
+// longest wave, does use it.)
+template <int HALO, int LOCAL>
 __global__ void __launch_bounds__(256, 5) k_nn_filter(const LinArgs a) {
     PoseK P;
     if (!load_pose<false>(a, P)) return;
     auto body = [&](int64_t first, int64_t end) {
         const int64_t i = first + (threadIdx.x & 63);
-        if (i < end) nn_point_filter<HALO, SETTLE>(a, P, i);
+        if (i < end) nn_point_filter<HALO, 0>(a, P, i);
     };
     nn_tile_loop<LOCAL, 64>(a, body);
 }
-// ... and the float64 search of what it could not certify; returns at once when no lane of this pass asked
+#ifdef PCR_DEV
+// ... and the float64 search of what it could not certify as a launch of its own (round 3; now only in front of the
+// unfused developer reduce kernels); returns at once when no lane of this pass asked
 __global__ void __launch_bounds__(256) k_nn_fix(const LinArgs a) {
     PoseK P;
     if (!load_pose<false>(a, P)) return;
     if (__builtin_amdgcn_readfirstlane(*(volatile const uint32_t *)a.pending) != a.stamp) return;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256)
-        if (a.nn_j[i] == PCR_PENDING) nn_point_fix(a, P, i);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
+        const uint32_t j = a.nn_j[i];
+        if (nn_is_pending(j)) nn_point_fix(a, P, i, j & ~PCR_PENDING_BIT);
+    }
 }
-static void launch_nn_filter(bool halo, int local, bool settle, bool separate_fix, dim3 grid, hipStream_t st, const LinArgs &a) {
+#endif
+static void launch_nn_filter(bool halo, int local, bool separate_fix, dim3 grid, hipStream_t st, const LinArgs &a) {
     const dim3 block(256);
-#define PCR_NF_CASE(H, L) do { if (settle) hipLaunchKernelGGL((k_nn_filter<H, L, 1>), grid, block, 0, st, a); \
-                               else hipLaunchKernelGGL((k_nn_filter<H, L, 0>), grid, block, 0, st, a); } while (0)
+#define PCR_NF_CASE(H, L) hipLaunchKernelGGL((k_nn_filter<H, L>), grid, block, 0, st, a)
     // (local == 2, "decided on the device from the size of the step", is not instantiated here: both tile loops in one
     // kernel around the tracking search spill 736 bytes per lane; the device-resident loop keeps the global counters)
     if (halo) { if (local == 1) PCR_NF_CASE(1, 1); else PCR_NF_CASE(1, 0); }
@@ -219,7 +227,11 @@ static void launch_nn_filter(bool halo, int local, bool settle, bool separate_fi
 #undef PCR_NF_CASE
     // the float64 search of the pending points: the prologue of k_reduce_finalize<KIND, 1> (round 4); a launch of its own
     // only in front of the unfused developer reduce kernels
+#ifdef PCR_DEV
     if (separate_fix) hipLaunchKernelGGL(k_nn_fix, grid, block, 0, st, a);
+#else
+    (void)separate_fix;
+#endif
 }
 
 // host-side choice of the instantiation
@@ -323,7 +335,7 @@ __device__ __forceinline__ void fix_pending(const LinArgs &a, const PoseK &P, co
         const bool more = i0 < it.end;                          // block-uniform
         if (more) {
             const int64_t i = i0 + threadIdx.x;
-            const bool pend = i < it.end && a.nn_j[i] == PCR_PENDING;
+            const bool pend = i < it.end && nn_is_pending(a.nn_j[i]);
             const unsigned long long m = __ballot(pend);
             if (m == 0) continue;
             if (pend) lst[cnt + __popcll(m & below)] = (uint32_t)(i - base0);
@@ -335,7 +347,10 @@ __device__ __forceinline__ void fix_pending(const LinArgs &a, const PoseK &P, co
             break;
         }
         // a full wave of pending points, or the end of the range: search what is listed (ONE inlined copy of the search)
-        if (lane < cnt) nn_point_fix(a, P, base0 + (int64_t)lst[lane]);
+        if (lane < cnt) {
+            const int64_t ip = base0 + (int64_t)lst[lane];
+            nn_point_fix(a, P, ip, a.nn_j[ip] & ~PCR_PENDING_BIT);
+        }
         const uint32_t carry = lane + 64 < cnt ? lst[lane + 64] : 0u;
         __builtin_amdgcn_wave_barrier();
         lst[lane] = carry;
@@ -437,10 +452,15 @@ pcr_status pcr_ensure_scratch(pcr_context *ctx, int64_t n_points) {
         HIP_TRY(hipMemsetAsync(ctx->d_tile_ctr, 0, sizeof(uint32_t) * ctr_words, ctx->stream));
         for (int v = 0; v < 4; ++v) {
             int nb = 0;
-            if (v == 2) { ctx->nn_blocks_per_cu[v] = pcr_dev_coop_blocks_per_cu(); continue; }
+            if (v == 2) {
+#ifdef PCR_DEV
+                ctx->nn_blocks_per_cu[v] = pcr_dev_coop_blocks_per_cu();
+#endif
+                continue;
+            }
             hipError_t e = v == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<0, 1, 0, 0>, 256, 0)
                          : v == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<1, 0, 0, 0>, 256, 0)
-                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_filter<1, 0, 0>, 256, 0);
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_filter<1, 0>, 256, 0);
             ctx->nn_blocks_per_cu[v] = (e == hipSuccess && nb > 0) ? nb : 4;
         }
     }
@@ -571,7 +591,11 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
     // TileIter and the ticket counts of k_reduce_finalize need a multiple of 8 blocks
     a.nblocks &= ~7;
     if (a.nblocks < 8) a.nblocks = 8;
+#ifdef PCR_DEV
     ps->fused_fin = ctx->fuse_finalize;
+#else
+    ps->fused_fin = true;                       // (the unfused folds live in kernels_dev.hip: developer build only)
+#endif
     ps->nn_mode = PCR_NN_FULL;
     ps->motion = -1.0;
     ps->gn_inline = false;
@@ -641,8 +665,10 @@ static void launch_reduce_kind(const Pass *ps, bool fused, bool fix, dim3 grid) 
             return;
         }
     }
-    if (fused) hipLaunchKernelGGL((k_reduce_finalize<KIND, 0>), grid, dim3(256), 0, ps->ctx->stream, ps->a, ps->f);
-    else pcr_dev_launch_reduce(KIND, grid, ps->ctx->stream, ps->a);
+#ifdef PCR_DEV
+    if (!fused) { pcr_dev_launch_reduce(KIND, grid, ps->ctx->stream, ps->a); return; }
+#endif
+    hipLaunchKernelGGL((k_reduce_finalize<KIND, 0>), grid, dim3(256), 0, ps->ctx->stream, ps->a, ps->f);
 }
 
 // enqueue the kernels of one pass on the context's stream (no waiting)
@@ -665,9 +691,12 @@ static pcr_status pass_enqueue(Pass *ps) {
         else { if (halo) PCR_LIN_LAUNCH(K, 1, 0, F); else PCR_LIN_LAUNCH(K, 0, 0, F); }
 #define PCR_LIN_CASE(K) PCR_LIN_CASE_F(K, 0)
 #define PCR_LIN_CASE_V(K) if (filt) { PCR_LIN_CASE_F(K, 1) } else { PCR_LIN_CASE_F(K, 0) }
+#ifdef PCR_DEV
         if (!ps->fused_fin) {
             pcr_dev_launch_linearize(ps->kind, halo, grid, ctx->stream, a);
-        } else switch (ps->kind) {
+        } else
+#endif
+        switch (ps->kind) {
         case PCR_ICP: PCR_LIN_CASE(PCR_ICP) break;
         case PCR_PLANE: PCR_LIN_CASE(PCR_PLANE) break;
         case PCR_VPLANE: PCR_LIN_CASE_V(PCR_VPLANE) break;
@@ -714,9 +743,12 @@ static pcr_status pass_enqueue(Pass *ps) {
             }
             if (ctx->tile_local >= 0) local = ctx->tile_local;
             ps->a.sched_local = local;
+#ifdef PCR_DEV
             if (!vox && ctx->nn_mode == 2) {
                 pcr_dev_launch_coop(nn_grid, ctx->stream, a);
-            } else if (!vox) {
+            } else
+#endif
+            if (!vox) {
                 launch_nn_scan<0>(mode, ps->t->cs_h != nullptr, ps->a.sched_local, nn_grid, ctx->stream, a);
             } else if (filter) {
                 if (++ctx->filter_stamp == 0) {                    // (wrapped after 2^32 passes: start over)
@@ -724,7 +756,7 @@ static pcr_status pass_enqueue(Pass *ps) {
                     ctx->filter_stamp = 1;
                 }
                 ps->a.stamp = ctx->filter_stamp;
-                launch_nn_filter(ps->t->filter->cs_h != nullptr, ps->a.sched_local, ctx->filter_settle != 0, !ps->fused_fin, nn_grid, ctx->stream, a);
+                launch_nn_filter(ps->t->filter->cs_h != nullptr, ps->a.sched_local, !ps->fused_fin, nn_grid, ctx->stream, a);
             } else if (ps->t->gd.rowocc != nullptr && (ctx->vox_occ >= 0 ? ctx->vox_occ != 0 : a.md_d / ps->t->gd.h + 2.0 >= 5.0)) {
                 launch_nn_scan<2>(mode, false, ps->a.sched_local, nn_grid, ctx->stream, a);
             } else {
@@ -745,9 +777,11 @@ static pcr_status pass_enqueue(Pass *ps) {
     }
     HIP_TRY(hipGetLastError());
     if (!ps->fused_fin) {
+#ifdef PCR_DEV
         pcr_prof_begin(ctx, PCR_K_FINALIZE, &ev);
         pcr_dev_launch_finalize(ctx->stream, ps->f);
         pcr_prof_end(ctx, &ev);
+#endif
         HIP_TRY(hipGetLastError());
     }
     return PCR_OK;

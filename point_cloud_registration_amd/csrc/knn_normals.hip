@@ -40,13 +40,28 @@ __device__ __forceinline__ void knn_offer(KnnList &L, float dist2, uint32_t jj, 
     if (L.cnt == L.k) { kth = L.D(L.k - 1); kth_o = L.O(L.k - 1); }
 }
 
+// Candidates are fetched KNN_BATCH at a time (independent loads in flight before the first compare: the search is a chain
+// of dependent round trips, one per candidate before round 4 -- k_knn_normals 1.49 ms per 1.06 M points at 5 % of the VALU
+// rate).  A batch may read past the end of the range: those records exist (the array carries PCR_PTS_PAD sentinels behind
+// its last point) but are NOT offered -- unlike in the 1-NN search a point of a later cell offered twice would sit in the
+// list twice.
+#ifndef KNN_BATCH
+#define KNN_BATCH 4
+#endif
 __device__ __forceinline__ void knn_scan_range(KnnList &L, const PtF *__restrict__ pts, uint32_t s, uint32_t e,
                                                float qx, float qy, float qz, float &kth, uint32_t &kth_o) {
-    for (uint32_t j = s; j < e; ++j) {
-        const PtF p = pts[j];
-        const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-        const float d = dist2_f32(dx, dy, dz);
-        knn_offer(L, d, j, pt_orig(p), kth, kth_o);
+    for (uint32_t j = s; j < e; j += KNN_BATCH) {
+        PtF p[KNN_BATCH];
+#pragma unroll
+        for (int u = 0; u < KNN_BATCH; ++u) p[u] = pts[j + u];
+#pragma unroll
+        for (int u = 0; u < KNN_BATCH; ++u) {
+            if (j + u < e) {
+                const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
+                const float d = dist2_f32(dx, dy, dz);
+                knn_offer(L, d, j + u, pt_orig(p[u]), kth, kth_o);
+            }
+        }
     }
 }
 

@@ -358,6 +358,9 @@ struct TileIter {
 // for small ones, where a pass is a chain of dependent cold misses rather than a throughput problem: one
 // launch less, no round trip of the matches through HBM (100 k-point scan: 48.8 vs 58.9 us per pass).
 // The host picks per launch (pcr_set_variant: 2 = automatic, the default).
+template <int HALO, int SETTLE, int B>
+__device__ __forceinline__ bool nn_filter_core(const LinArgs &a, float tx, float ty, float tz, uint32_t &w, double &d);
+
 // FILT (voxel kinds, round 4): the centroid search runs the float32 filter search with two-way settling (nn_filter_core)
 // and falls back to the float64 search inline for what that cannot certify (a third centroid inside the margin: rare
 // enough that the extra chain does not show); HALO then says whether the FILTER index has the extended lists.
@@ -558,7 +561,8 @@ __device__ __forceinline__ void nn_point(const LinArgs &a, const PoseK &P, const
 // is left to k_nn_fix, the launch behind this one: nn_j = PCR_PENDING, and the pass' stamp goes into a.pending so that
 // k_nn_fix returns at once when no lane asked (it runs the float64 search for the pending points: identical results by
 // construction, `test_centroid_filter_is_exact`).  Inlining that search here instead cost 96 VGPRs + 140 spilled SGPRs.
-#define PCR_PENDING 0xfffffffeu
+#define PCR_PENDING_BIT 0x80000000u       // nn_j of a point the filter could not certify: this bit + the filter's nominee
+__device__ __forceinline__ bool nn_is_pending(uint32_t j) { return (j & PCR_PENDING_BIT) != 0 && j != PCR_NONE; }
 // SETTLE (round 4): the tracking search also carries the RUNNER-UP's index and a bound on everybody but the first two
 // (NNTrack::third, nn_test_f32<2>).  A lane whose winner cannot be certified alone -- two rounded centroids within the
 // margin of the same distance -- computes the runner-up's float64 distance too, takes the nearer of the two by the float64
@@ -566,7 +570,7 @@ __device__ __forceinline__ void nn_point(const LinArgs &a, const PoseK &P, const
 // third candidate inside the margin is left pending.
 // (the search + check for one transformed point: returns true when the answer is CERTIFIED -- w = cell-sorted index of the
 // nearest centroid or PCR_NONE when nothing lies within the search bound, d = its squared float64 distance)
-template <int HALO, int SETTLE, int B = PCR_NN_BATCH>
+template <int HALO, int SETTLE, int B>
 __device__ __forceinline__ bool nn_filter_core(const LinArgs &a, float tx, float ty, float tz, uint32_t &w, double &d) {
     uint32_t fj = PCR_NONE, fo = PCR_NONE;
     float best = a.bound2_ff;
@@ -600,24 +604,60 @@ __device__ __forceinline__ void nn_point_filter(const LinArgs &a, const PoseK &P
     float tx, ty, tz;
     xform(P, x, y, z, tx, ty, tz);
     uint32_t w; double d;
-    const bool cert = nn_filter_core<HALO, SETTLE>(a, tx, ty, tz, w, d);
+    const bool cert = nn_filter_core<HALO, SETTLE, PCR_NN_BATCH>(a, tx, ty, tz, w, d);
     uint32_t out = (w != PCR_NONE && __builtin_sqrt(d) < a.md_d) ? w : PCR_NONE;
     if (!cert) {
-        out = PCR_PENDING;
+        out = PCR_PENDING_BIT | w;                   // (cert is only ever false with a nominee: w != PCR_NONE)
         atomicMax(a.pending, a.stamp);
     }
     a.nn_j[i] = out;
 }
 
-// the float64 search for the points nn_point_filter could not certify
-__device__ __forceinline__ void nn_point_fix(const LinArgs &a, const PoseK &P, int64_t i) {
+// The float64 answer for a point nn_point_filter could not certify.  The filter left its NOMINEE behind (nn_j =
+// PCR_PENDING_BIT | index): the exact nearest centroid is the lexicographic minimum of (float64 distance, original index)
+// over the centroids inside the ball through the nominee, which usually touches a handful of cells.  A from-scratch ring
+// search bounded by the gate is a chain of ~50 dependent round trips (two per row of cells: entry, then records) --
+// 50-65 us with the rest of the chip idle, whatever the number of pending points; here the entries of the (at most 3 x 3)
+// rows of the ball's cell box are requested together and the rows scanned with the nominee as the running best:
+// ~5 round trips.  Larger boxes (a nominee near the gate) take the ring search, seeded with the nominee.
+__device__ __forceinline__ void nn_point_fix(const LinArgs &a, const PoseK &P, int64_t i, uint32_t nominee) {
     float tx, ty, tz;
     xform(P, a.sx[i], a.sy[i], a.sz[i], tx, ty, tz);
-    double bd = a.bound2_d;
-    uint32_t bj = PCR_NONE, bo = PCR_NONE;
-    nn_search<double, PtD, false, false, false, false, false>(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz,
-                                                              a.bound2_d, bd, bj, bo);
-    a.nn_j[i] = (bo != PCR_NONE && __builtin_sqrt(bd) < a.md_d) ? bj : PCR_NONE;
+    const double qx = (double)tx, qy = (double)ty, qz = (double)tz;
+    const Geom<double> &g = a.gd;
+    const PtD mA = a.means[nominee];
+    double bd;
+    uint32_t bj = nominee, bo = pt_orig(mA);
+    {
+        const double dx = qx - mA.x, dy = qy - mA.y, dz = qz - mA.z;
+        bd = (dx * dx + dy * dy) + dz * dz;                           // nn_test<double>'s expression
+    }
+    const double r = __builtin_sqrt(bd) * 1.0000001 + g.slack;
+    const double lim = 1.0e9;
+    auto cell = [&](double v, double o, int n) {
+        const double c = fmin(fmax((v - o) * g.inv_h, -lim), lim);
+        return min(max((int)floor(c), 0), n - 1);
+    };
+    const int xl = cell(qx - r, g.ox, g.nx), xh = cell(qx + r, g.ox, g.nx);
+    const int yl = cell(qy - r, g.oy, g.ny), yh = cell(qy + r, g.oy, g.ny);
+    const int zl = cell(qz - r, g.oz, g.nz), zh = cell(qz + r, g.oz, g.nz);
+    if (yh - yl <= 2 && zh - zl <= 2) {
+        const uint32_t unx = (uint32_t)g.nx, plane = (uint32_t)g.ny * unx;
+        uint32_t s_[9], e_[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {                                 // all entries in flight at once
+            const int y = yl + k % 3, z = zl + k / 3;
+            const bool live = y <= yh && z <= zh;
+            const uint32_t row = (uint32_t)(live ? z : zl) * plane + (uint32_t)(live ? y : yl) * unx;
+            const uint32_t s0 = a.cell_start[row + (uint32_t)xl] & g.cs_mask, e0 = a.cell_start[row + (uint32_t)xh + 1u] & g.cs_mask;
+            s_[k] = s0; e_[k] = live ? e0 : s0;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) nn_scan_range<double, PtD, 0>(a.means, s_[k], e_[k], qx, qy, qz, bd, bj, bo);
+    } else {
+        nn_search<double, PtD, false, true, false, 0, false>(g, a.means, a.cell_start, qx, qy, qz, bd * 1.0000001, bd, bj, bo);
+    }
+    a.nn_j[i] = __builtin_sqrt(bd) < a.md_d ? bj : PCR_NONE;
 }
 
 // ---- fold the per-block partials in a fixed order and emit the 29-vector ---------------------

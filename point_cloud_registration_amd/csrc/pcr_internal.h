@@ -205,7 +205,6 @@ struct pcr_context {
     double voxel_cell_mult = 2.0; // PCR_VOXEL_CELL_MULT: centroid grid cell edge in voxels
     int vox_filter = 1;          // PCR_VOX_FILTER=0: plain passes search the centroids in float64 (no float32 filter)
     int filter_after = 8;        // PCR_FILTER_AFTER: fused small-scan passes a voxel target serves before its filter index is built
-    int filter_settle = 0;       // PCR_FILTER_SETTLE: the filter search settles two-way near-ties itself (nn_point_filter<SETTLE>)
     int vox_occ = -1;            // PCR_VOX_OCC (developer): force the centroid search's row-bitmap variant on / off; -1 = by gate / cell ratio
     int tile_local = -1;         // PCR_TILE_LOCAL (developer): force the hand-out policy of k_nn_scan; -1 = automatic
     int reuse = 1;               // 0 off, 1 automatic, 2 forced (track + list whenever the state allows: tests)

@@ -30,15 +30,28 @@ class PlaneICP(Registration):
         self.target = target.astype(np.float32)
         self.kdtree = KDTree(self.target, device=self._device, _ctx=self._ctx())
         if kdree is None or norm is None:
-            # k-NN PCA normals on the GPU (estimate_normals.py:27-87)
-            self.normal = self.kdtree._target.estimate_normals(self.k, compat=self._compat_normals)
+            # k-NN PCA normals on the GPU (estimate_normals.py:27-87).  They stay there: ``self.normal`` (the attribute the
+            # reference sets, plane_icp.py:23-24) reads them back the first time somebody asks -- 12.7 MB over PCIe per
+            # 1.06 M points, 0.35 ms of a 3.4 ms set_target that align() never needs
+            self.kdtree._target.estimate_normals(self.k, compat=self._compat_normals, want=False)
+            self._normal = None
         else:
-            self.normal = np.asarray(norm)
-            if self.normal.shape != self.target.shape:
+            self._normal = np.asarray(norm)
+            if self._normal.shape != self.target.shape:
                 raise ValueError("norm must have the shape of the target")
-            self.kdtree._target.set_normals(self.normal)
+            self.kdtree._target.set_normals(self._normal)
         self._target = self.kdtree._target
         self._is_target_set = True
+
+    @property
+    def normal(self):
+        if getattr(self, "_normal", None) is None and getattr(self, "_target", None) is not None:
+            self._normal = self._target.get_normals()
+        return getattr(self, "_normal", None)
+
+    @normal.setter
+    def normal(self, value):
+        self._normal = value
 
     def calc_H_g_e2_no_parallel_ver(self, cur_T, source):
         """Per-point loop of the same sums (the reference keeps one, plane_icp.py:72-101); host Python

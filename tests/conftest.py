@@ -98,11 +98,19 @@ PIPELINES = {
 }
 
 
+# pipelines that need the developer kernels of csrc/kernels_dev.hip: only libpcr_hip_dev.so (`make dev`) has them.  The
+# shipped library runs the others; tests/test_gpu_dev_build.py re-runs every pipeline test in a process that loaded the
+# developer build (PCR_LIB).
+DEV_PIPELINES = ("coop", "unfused", "onekernel_unfused")
+
+
 @pytest.fixture(params=list(PIPELINES))
 def pipeline(request):
     """Runs the test once per kernel pipeline on the process-wide context of device 0, restoring the
     shipped selection afterwards."""
     from point_cloud_registration_amd import _capi
+    if request.param in DEV_PIPELINES and not _capi.has_dev_kernels():
+        pytest.skip("developer pipeline: runs in the developer build (tests/test_gpu_dev_build.py)")
     ctx = _capi.get_context(0)
     before = ctx.get_pipeline()
     with ctx.pipeline(**PIPELINES[request.param]):

@@ -8,11 +8,13 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 src=$root/point_cloud_registration_amd/csrc
 out=$root/build/exp/$name
 mkdir -p "$out"
-flags="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -I$root/include -I$src $defs"
+flags="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -I$root/include -I$src -DPCR_DEV=1 $defs"
 pids=()
 for f in api kernels kernels_dev index_build comm voxel_build knn_normals host_hash; do
     # only kernels.hip sees the experiment macros; the other objects are reused from the main build when present
-    if [ "$f" != "kernels" ] && [ -f "$src/$f.o" ] && [ -z "$ALL" ]; then cp "$src/$f.o" "$out/$f.o"; continue; fi
+    # (variant libraries are developer builds: api / kernels / kernels_dev are compiled with -DPCR_DEV)
+    if [ "$f" != "kernels" ] && [ -f "$src/$f.dev.o" ] && [ -z "$ALL" ]; then cp "$src/$f.dev.o" "$out/$f.o"; continue; fi
+    if [ "$f" != "kernels" ] && [ "$f" != "api" ] && [ "$f" != "kernels_dev" ] && [ -f "$src/$f.o" ] && [ -z "$ALL" ]; then cp "$src/$f.o" "$out/$f.o"; continue; fi
     /opt/rocm/bin/hipcc $flags -c "$src/$f.hip" -o "$out/$f.o" &
     pids+=($!)
 done

@@ -10,6 +10,7 @@ from point_cloud_registration_amd.synthetic import street, perturbed_scan
 pose = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 big = len(sys.argv) > 2 and sys.argv[2] == "100m"        # the 1e8-point target with a 12.5 M-point scan
 ctx = _capi.get_context(0)
+ctx.set_reuse(0)                        # every pass a plain full search (40 passes at one pose would otherwise be certified)
 if big:
     from point_cloud_registration_amd.synthetic import street_tiled
     target = street_tiled(100_000_000, seed=0)
