@@ -218,6 +218,10 @@ PCR_API pcr_status pcr_target_index_info(pcr_target *t, double *cell, int64_t di
  * fraction of the cell edge, default 0.1, 0 = none).  Voxel targets: the same of the float32 filter index over
  * the rounded centroids (both 0: the target has no filter -- coordinates too large -- and searches in float64) */
 PCR_API pcr_status pcr_target_index_halo(pcr_target *t, double *halo, int64_t *records);
+/* point targets: the same of the second, deeper set of lists (margin 0.25 x cell), which the library builds once a target
+ * has served a dozen search + reduce passes and which serves the passes of a Gauss-Newton run whose scan still moves by
+ * more than 0.12 cell per pass; both 0 while it does not exist                                                         */
+PCR_API pcr_status pcr_target_index_halo2(pcr_target *t, double *halo, int64_t *records);
 /* voxel targets: the bound (metres) on how far rounding to float32 moved any centroid of the filter index -- what the
  * float32 filter search of the centroid search (voxel.py:171-179) subtracts from its lower bounds before the float64
  * check; 1.75 x 2^-24 x the largest coordinate magnitude of the centroid grid.  0 = no filter index (not built yet:

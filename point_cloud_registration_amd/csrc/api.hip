@@ -445,7 +445,7 @@ static void target_free(pcr_target *t) { pcr_target_release(t); }
 void pcr_target_release(pcr_target *t) {
     if (!t) return;
     target_free(t->filter);
-    void *ptrs[] = {t->cell_start, t->cell_seed, t->rowocc, t->cs_h, t->pts_h, t->j_h, t->pts, t->pn, t->means, t->vnorm, t->vicov,
+    void *ptrs[] = {t->cell_start, t->cell_seed, t->rowocc, t->cs_h, t->pts_h, t->j_h, t->cs_h2, t->pts_h2, t->j_h2, t->pts, t->pn, t->means, t->vnorm, t->vicov,
                     t->st_mean, t->st_cov, t->st_norm, t->st_icov, t->st_counts, t->st_keys};
     if (t->ctx) (void)hipSetDevice(t->ctx->device);
     for (void *p : ptrs) pcr_persist_free(t->ctx, p);
@@ -619,6 +619,13 @@ extern "C" pcr_status pcr_target_index_halo(pcr_target *t, double *halo, int64_t
     const pcr_target *p = t->is_voxel ? t->filter : t;      // voxel targets: the float32 filter index of the centroid search
     if (halo) *halo = p ? (double)p->gf.halo : 0.0;
     if (records) *records = p ? p->n_h : 0;
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_target_index_halo2(pcr_target *t, double *halo, int64_t *records) {
+    PCR_REQUIRE(t, "NULL argument");
+    if (halo) *halo = t->is_voxel ? 0.0 : (double)t->halo2;
+    if (records) *records = t->is_voxel ? 0 : t->n_h2;
     return PCR_OK;
 }
 

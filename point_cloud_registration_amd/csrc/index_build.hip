@@ -335,6 +335,49 @@ static int bits_for(double ncells) {
     return b;
 }
 
+// Extended per-cell lists of a finished point grid (cell-sorted points `pts`, cell_start `cs` with its gap bits) for
+// a halo margin of halo_frac x cell.  n_h = 0 (and no buffers) when the copies would not fit the 28-bit offsets.
+static pcr_status build_halo_lists(pcr_context *ctx, Geom<float> gh, const PtF *pts, int64_t n, const uint32_t *cs, double halo_frac,
+                                   DevBuf<uint32_t> *cs_h, DevBuf<PtF> *pts_h, DevBuf<uint32_t> *j_h, int64_t *n_h_out) {
+    *n_h_out = 0;
+    const size_t ncells = (size_t)gh.nx * (size_t)gh.ny * (size_t)gh.nz;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    gh.halo = (float)(fmin(halo_frac, 1.0) * (double)gh.h);     // (1.0: a cell's list = all points of its 27-cell block)
+    const size_t nc1 = ncells + 1;
+    HIP_TRY(cs_h->alloc_exact(nc1));
+    HIP_TRY(hipMemsetAsync(cs_h->p, 0, sizeof(uint32_t) * nc1, ctx->stream));
+    hipLaunchKernelGGL(k_halo_count, dim3(nb), dim3(256), 0, ctx->stream, pts, n, gh, cs_h->p);
+    HIP_TRY(hipGetLastError());
+    PCR_TRY(exclusive_scan_u32(ctx, cs_h->p, (int64_t)nc1));
+    uint32_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, cs_h->p + (nc1 - 1), sizeof total, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if ((int64_t)total >= ((int64_t)1 << PCR_GAP_SHIFT)) {     // too many copies for 28-bit offsets: no lists
+        cs_h->reset();
+        return PCR_OK;
+    }
+    const int64_t n_h = (int64_t)total;
+    DevBuf<uint32_t> cursor;
+    HIP_TRY(cursor.alloc(nc1));
+    HIP_TRY(hipMemcpyAsync(cursor.p, cs_h->p, sizeof(uint32_t) * nc1, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(pts_h->alloc_exact((size_t)n_h + PCR_PTS_PAD));
+    HIP_TRY(j_h->alloc_exact((size_t)n_h + PCR_PTS_PAD));
+    {
+        PtF pad[PCR_PTS_PAD];
+        for (int i = 0; i < PCR_PTS_PAD; ++i) {
+            pad[i].x = pad[i].y = pad[i].z = INFINITY;
+            const uint32_t m = 0xffffffffu; memcpy(&pad[i].w, &m, 4);
+        }
+        HIP_TRY(hipMemcpyAsync(pts_h->p + (size_t)n_h, pad, sizeof pad, hipMemcpyHostToDevice, ctx->stream));
+    }
+    hipLaunchKernelGGL(k_halo_fill, dim3(nb), dim3(256), 0, ctx->stream, pts, n, gh, cursor.p, pts_h->p, j_h->p);
+    hipLaunchKernelGGL(k_gap_copy, dim3((unsigned)((nc1 + 255) / 256)), dim3(256), 0, ctx->stream, cs, cs_h->p, (int64_t)nc1, gh.cs_mask);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *n_h_out = n_h;
+    return PCR_OK;
+}
+
 // Shared build: pick h (auto: average occupancy of the occupied cells in [3, 10]), histogram,
 // prefix, stable radix sort by cell id, gather.
 template <typename Real, typename T, typename PT>
@@ -458,40 +501,8 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
     if (sizeof(Real) == 4 && halo_frac > 0 && n > 0 && g.cs_mask != 0xffffffffu) {
         Geom<float> gh;
         memcpy(&gh, &g, sizeof gh);                           // Real == float here
-        gh.halo = (float)(fmin(halo_frac, 1.0) * (double)g.h);     // (1.0: a cell's list = all points of its 27-cell block)
-        const size_t nc1 = (size_t)ncells + 1;
-        HIP_TRY(d_cs_h.alloc_exact(nc1));
-        HIP_TRY(hipMemsetAsync(d_cs_h.p, 0, sizeof(uint32_t) * nc1, ctx->stream));
-        hipLaunchKernelGGL(k_halo_count, dim3(nb), dim3(256), 0, ctx->stream, (const PtF *)d_pts.p, n, gh, d_cs_h.p);
-        HIP_TRY(hipGetLastError());
-        PCR_TRY(exclusive_scan_u32(ctx, d_cs_h, (int64_t)nc1));
-        uint32_t total = 0;
-        HIP_TRY(hipMemcpyAsync(&total, d_cs_h.p + (nc1 - 1), sizeof total, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if ((int64_t)total < ((int64_t)1 << PCR_GAP_SHIFT)) {
-            n_h = (int64_t)total;
-            DevBuf<uint32_t> cursor;
-            HIP_TRY(cursor.alloc(nc1));
-            HIP_TRY(hipMemcpyAsync(cursor.p, d_cs_h.p, sizeof(uint32_t) * nc1, hipMemcpyDeviceToDevice, ctx->stream));
-            HIP_TRY(d_pts_h.alloc_exact((size_t)n_h + PCR_PTS_PAD));
-            HIP_TRY(d_j_h.alloc_exact((size_t)n_h + PCR_PTS_PAD));
-            {
-                PtF pad[PCR_PTS_PAD];
-                for (int i = 0; i < PCR_PTS_PAD; ++i) {
-                    pad[i].x = pad[i].y = pad[i].z = INFINITY;
-                    const uint32_t m = 0xffffffffu; memcpy(&pad[i].w, &m, 4);
-                }
-                HIP_TRY(hipMemcpyAsync(d_pts_h.p + (size_t)n_h, pad, sizeof pad, hipMemcpyHostToDevice, ctx->stream));
-            }
-            hipLaunchKernelGGL(k_halo_fill, dim3(nb), dim3(256), 0, ctx->stream, (const PtF *)d_pts.p, n, gh, cursor.p, d_pts_h.p, d_j_h.p);
-            hipLaunchKernelGGL(k_gap_copy, dim3((unsigned)((nc1 + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const uint32_t *)d_counts.p, d_cs_h.p, (int64_t)nc1, g.cs_mask);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-            g.halo = (Real)gh.halo; g.cs_h = d_cs_h.p; g.pts_h = d_pts_h.p; g.j_h = d_j_h.p;
-        } else {
-            d_cs_h.reset();                                   // too many copies for 28-bit offsets: no halo
-        }
+        PCR_TRY(build_halo_lists(ctx, gh, (const PtF *)d_pts.p, n, (const uint32_t *)d_counts.p, halo_frac, &d_cs_h, &d_pts_h, &d_j_h, &n_h));
+        if (n_h > 0) { g.halo = (Real)(fmin(halo_frac, 1.0) * (double)g.h); g.cs_h = d_cs_h.p; g.pts_h = d_pts_h.p; g.j_h = d_j_h.p; }
     }
     // success: hand the index over
     g.seed = d_seed.p;
@@ -540,10 +551,15 @@ static pcr_status make_row_occ(pcr_context *ctx, const uint32_t *cs, Geom<Real> 
     return PCR_OK;
 }
 
-pcr_status pcr_count_nonfinite(pcr_context *ctx, const void *d_xyz, int is_f64, int64_t n, int64_t *count) {
+pcr_status pcr_count_nonfinite(pcr_context *ctx, const void *d_xyz, int is_f64, int64_t n, int64_t *count, float *lo_out, float *hi_out) {
     float lo[3], hi[3];
-    if (is_f64) return device_bbox<double>(ctx, (const double *)d_xyz, n, lo, hi, count);
-    return device_bbox<float>(ctx, (const float *)d_xyz, n, lo, hi, count);
+    pcr_status s = is_f64 ? device_bbox<double>(ctx, (const double *)d_xyz, n, lo, hi, count)
+                          : device_bbox<float>(ctx, (const float *)d_xyz, n, lo, hi, count);
+    for (int a = 0; a < 3; ++a) {
+        if (lo_out) lo_out[a] = lo[a];
+        if (hi_out) hi_out[a] = hi[a];
+    }
+    return s;
 }
 
 pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n, float cell_hint, pcr_target *t, bool use_env) {
@@ -561,6 +577,21 @@ pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n,
     PCR_TRY((build_grid<float, float, PtF>(ctx, d_xyz, n, h, auto_h, &t->gf, &t->cell_start, &t->cell_seed, &t->pts, &t->occupied,
                                            halo, &t->cs_h, &t->pts_h, &t->j_h, &t->n_h)));
     return PCR_OK;       // (no row-occupancy bitmap for point targets: measured slower, nn_device.h)
+}
+
+// The second, DEEPER set of extended lists of a point target (halo PCR_HALO2_FRAC x cell), built by the first pass that
+// gets its cost back (kernels.hip: pass_setup); a pass picks one of the two sets by how far the scan moved.
+pcr_status pcr_build_deep_lists(pcr_context *ctx, pcr_target *t) {
+    if (t->is_voxel || !t->cs_h || t->n <= 0 || t->cs_h2) return PCR_OK;
+    DevBuf<uint32_t> cs_h, j_h;
+    DevBuf<PtF> pts_h;
+    int64_t n_h = 0;
+    PCR_TRY(build_halo_lists(ctx, t->gf, t->pts, t->n, t->cell_start, PCR_HALO2_FRAC, &cs_h, &pts_h, &j_h, &n_h));
+    if (n_h <= 0) return PCR_OK;
+    t->halo2 = (float)(PCR_HALO2_FRAC * (double)t->gf.h);
+    t->n_h2 = n_h;
+    t->cs_h2 = cs_h.release(); t->pts_h2 = pts_h.release(); t->j_h2 = j_h.release();
+    return PCR_OK;
 }
 
 pcr_status pcr_build_centroid_grid(pcr_context *ctx, const double *d_mean, int64_t n, double cell, pcr_target *t) {

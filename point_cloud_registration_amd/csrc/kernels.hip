@@ -126,7 +126,7 @@ __device__ __forceinline__ void nn_chunk_list(const LinArgs &a, const PoseK &P, 
     }
     __syncthreads();
     const uint32_t total = *lst_n;
-    for (uint32_t e = threadIdx.x; e < total; e += 256) nn_point<VOXEL, HALO, 1>(a, P, Q, first + (int64_t)lst[e]);
+    for (uint32_t e = threadIdx.x; e < total; e += 256) nn_point<VOXEL, HALO, 1>(a, a.gf, P, Q, first + (int64_t)lst[e]);
     __syncthreads();                                                // (the list is rewritten by the next chunk)
 }
 
@@ -176,9 +176,11 @@ __global__ void __launch_bounds__(256, VOXEL == 2 ? PCR_VOX_WAVES : 5) k_nn_scan
         __shared__ uint32_t lst_n;
         nn_chunk_loop(a, [&](int64_t first, int64_t end) { nn_chunk_list<VOXEL, HALO>(a, P, Q, lst, &lst_n, first, end); });
     } else {
+        // (LOCAL == 2 = the device-resident loop: the list set of this iteration was decided by k_gn_update)
+        const Geom<float> gsel = (!VOXEL && HALO && LOCAL == 2) ? select_lists(a) : a.gf;
         auto body = [&](int64_t first, int64_t end) {
             const int64_t i = first + (threadIdx.x & 63);
-            if (i < end) nn_point<VOXEL, HALO, MODE == PCR_NN_TRACK>(a, P, Q, i);
+            if (i < end) nn_point<VOXEL, HALO, MODE == PCR_NN_TRACK>(a, gsel, P, Q, i);
         };
         if (LOCAL == 2) {       // device-resident loop: k_gn_update decided from the size of its step (PoseDev::tile_local)
             if (__builtin_amdgcn_readfirstlane(a.pose->tile_local)) nn_tile_loop<1, 64>(a, body);
@@ -271,7 +273,9 @@ __device__ __forceinline__ void gn_update(const FinArgs &f, double (*A)[7]) {
     for (int i = 0; i < 16; ++i) T_old[i] = T[i];
     const int r = gn_step(A, f.out, f.tol, T);
     // hand-out policy of the next search (see pass_enqueue): block-local once the scan moves by less than local_len
-    p->tile_local = (r == 0 && f.local_len > 0.0 && gn_typical_motion(T_old, T, f.bb_c, f.bb_e) < f.local_len) ? 1 : 0;
+    const double moved = r == 0 ? gn_typical_motion(T_old, T, f.bb_c, f.bb_e) : 0.0;
+    p->tile_local = (r == 0 && f.local_len > 0.0 && moved < f.local_len) ? 1 : 0;
+    p->halo_deep = (r == 0 && moved >= f.deep_len) ? 1 : 0;
     int done = r == 2 ? PCR_LOOP_SINGULAR : (r == 1 ? PCR_LOOP_CONVERGED : PCR_LOOP_RUNNING);
     if (r == 0) {
         for (int i = 0; i < 16; ++i) p->T[i] = T[i];
@@ -316,6 +320,7 @@ __global__ void __launch_bounds__(64) k_pose_init(PoseDev *p, const PoseInit ini
     p->iter = 0;
     p->done = max_iter > 0 ? PCR_LOOP_RUNNING : PCR_LOOP_MAXITER;
     p->tile_local = 0;
+    p->halo_deep = 1;          // the first pass knows nothing about its distance to the target: the deeper lists (equal there)
 }
 
 // The pending points of a filter pass (1-2 per 1000) inside the range of scan points this thread is about to reduce.
@@ -331,34 +336,54 @@ __device__ __forceinline__ void fix_pending(const LinArgs &a, const PoseK &P, co
     const int64_t base0 = it.base - threadIdx.x;               // first point of this block's first tile
     const unsigned long long below = (1ull << lane) - 1ull;
     int cnt = 0;                                                // wave-uniform
-    for (int64_t i0 = base0;; i0 += it.stride) {
+    // FIX_UNROLL words of nn_j are requested before the first is looked at: one word per round trip made the walk itself a
+    // chain of ~38 dependent loads per wave (10 M points over 1024 blocks), 55-60 us -- as long as the searches it feeds
+    constexpr int FIX_UNROLL = 8;
+    for (int64_t i0 = base0;; i0 += FIX_UNROLL * it.stride) {
         const bool more = i0 < it.end;                          // block-uniform
         if (more) {
-            const int64_t i = i0 + threadIdx.x;
-            const bool pend = i < it.end && nn_is_pending(a.nn_j[i]);
-            const unsigned long long m = __ballot(pend);
-            if (m == 0) continue;
-            if (pend) lst[cnt + __popcll(m & below)] = (uint32_t)(i - base0);
-            cnt += __popcll(m);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (cnt < 64) continue;
-        } else if (cnt == 0) {
-            break;
+            uint32_t jv[FIX_UNROLL];
+#pragma unroll
+            for (int u = 0; u < FIX_UNROLL; ++u) {
+                const int64_t i = i0 + (int64_t)u * it.stride + threadIdx.x;
+                jv[u] = i < it.end ? a.nn_j[i] : PCR_NONE;
+            }
+#pragma unroll
+            for (int u = 0; u < FIX_UNROLL; ++u) {
+                const bool pend = nn_is_pending(jv[u]);
+                const unsigned long long m = __ballot(pend);
+                if (m == 0) continue;
+                if (pend) lst[cnt + __popcll(m & below)] = (uint32_t)(i0 + (int64_t)u * it.stride + threadIdx.x - base0);
+                cnt += __popcll(m);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (cnt >= 64) {                                // a full wave of pending points: search them now
+                    const int64_t ip = base0 + (int64_t)lst[lane];
+#ifdef PCR_DEV
+                    if (a.flags & (1u << 28)) a.nn_j[ip] &= ~PCR_PENDING_BIT;      // (PCR_FIX_DEBUG=1, timing only: the walk without the searches)
+                    else
+#endif
+                    nn_point_fix(a, P, ip, a.nn_j[ip] & ~PCR_PENDING_BIT);
+                    const uint32_t carry = lane + 64 < cnt ? lst[lane + 64] : 0u;
+                    __builtin_amdgcn_wave_barrier();
+                    lst[lane] = carry;
+                    cnt -= 64;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            continue;
         }
-        // a full wave of pending points, or the end of the range: search what is listed (ONE inlined copy of the search)
+        // the end of the range: what is still listed (fewer than 64)
         if (lane < cnt) {
             const int64_t ip = base0 + (int64_t)lst[lane];
+#ifdef PCR_DEV
+            if (a.flags & (1u << 28)) a.nn_j[ip] &= ~PCR_PENDING_BIT;
+            else
+#endif
             nn_point_fix(a, P, ip, a.nn_j[ip] & ~PCR_PENDING_BIT);
         }
-        const uint32_t carry = lane + 64 < cnt ? lst[lane + 64] : 0u;
-        __builtin_amdgcn_wave_barrier();
-        lst[lane] = carry;
-        cnt = cnt > 64 ? cnt - 64 : 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (!more && cnt == 0) break;
-        if (!more) i0 -= it.stride;                             // (stay behind the end until the list is empty)
+        break;
     }
 }
 
@@ -576,6 +601,15 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
         a.gf = t->filter->gf; a.pts = t->filter->pts; a.cs_f = t->filter->cell_start;
         a.band_f = (float)(t->filter_band * 1.000001);
     }
+    // the deeper set of extended lists of a point target: built once the target has served PCR_HALO2_AFTER search + reduce
+    // passes (a failed build is not an error: the pass runs on the first set)
+    if (!t->is_voxel && !one_kernel && t->cs_h && ctx->nn_mode == 0) {
+        if (!t->deep_tried && ++t->split_passes > PCR_HALO2_AFTER) {
+            t->deep_tried = true;
+            if (pcr_build_deep_lists(ctx, t) != PCR_OK) (void)hipGetLastError();
+        }
+        if (t->cs_h2) { a.cs_h2 = t->cs_h2; a.pts_h2 = t->pts_h2; a.j_h2 = t->j_h2; a.halo2_f = t->halo2; }
+    }
     a.md_f = (float)max_dist; a.md_d = max_dist;
     const double bound = max_dist * (1.0 + 1e-6);
     a.bound2_f = (float)(bound * bound); a.bound2_d = bound * bound;
@@ -603,6 +637,7 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
     memset(&f, 0, sizeof f);
     for (int i = 0; i < 3; ++i) { f.bb_c[i] = s->bb_c[i]; f.bb_e[i] = s->bb_e[i]; }
     f.local_len = ctx->local_frac * (t->is_voxel ? t->gd.h : (double)t->gf.h);
+    f.deep_len = PCR_HALO2_MOVE * (t->is_voxel ? t->gd.h : (double)t->gf.h);
     f.ucnt = s->ucnt; f.n_ucnt = a.nblocks;
     f.partials = ctx->d_partials; f.tile_ctr = ctx->d_tile_ctr + 9 * 16; f.tickets = ctx->d_tile_ctr; f.nblocks = a.nblocks; f.kind = kind; f.out = ctx->d_out;
     return PCR_OK;
@@ -674,6 +709,12 @@ static void launch_reduce_kind(const Pass *ps, bool fused, bool fix, dim3 grid) 
 // enqueue the kernels of one pass on the context's stream (no waiting)
 static pcr_status pass_enqueue(Pass *ps) {
     pcr_context *ctx = ps->ctx;
+#ifdef PCR_DEV
+    {   // developer timing experiments on the pending-point prologue (results are WRONG when set)
+        static const int dbg = getenv("PCR_FIX_DEBUG") ? atoi(getenv("PCR_FIX_DEBUG")) : 0;
+        if (dbg) ps->a.flags |= (unsigned)(dbg & 3) << 28;
+    }
+#endif
     const LinArgs &a = ps->a;
     const dim3 grid(a.nblocks), block(256);
     ProfEvent ev;
@@ -749,6 +790,10 @@ static pcr_status pass_enqueue(Pass *ps) {
             } else
 #endif
             if (!vox) {
+                // host-driven pass: the list set by how far the scan moved since the previous pass (unknown: the deeper one)
+                if (a.pose == nullptr && a.halo2_f > 0.f && mode == PCR_NN_FULL && !(ps->motion >= 0.0 && ps->motion < ps->f.deep_len)) {
+                    ps->a.gf.halo = a.halo2_f; ps->a.gf.cs_h = a.cs_h2; ps->a.gf.pts_h = a.pts_h2; ps->a.gf.j_h = a.j_h2;
+                }
                 launch_nn_scan<0>(mode, ps->t->cs_h != nullptr, ps->a.sched_local, nn_grid, ctx->stream, a);
             } else if (filter) {
                 if (++ctx->filter_stamp == 0) {                    // (wrapped after 2^32 passes: start over)
@@ -986,6 +1031,7 @@ pcr_status pcr_run_align(pcr_target *t, pcr_scan *s, int kind, const double T_in
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     const int done = loop_done(), it = passes_done();
+    if (!t->is_voxel && !ps.one_kernel) t->split_passes += it > 1 ? it - 1 : 0;     // (pass_setup counted one)
     for (int i = 0; i < 16; ++i) T_out[i] = ctx->h_out[40 + i];
     if (iterations) *iterations = it;
     if (trace_or_null && it > 0) {

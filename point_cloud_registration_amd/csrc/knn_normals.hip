@@ -15,29 +15,32 @@
 #define KNN_BLOCK 64
 #define KNN_MAX_K 64
 
+// (round 4: the original indices are no longer kept in LDS -- they only matter when two distances are EQUAL, and are then
+// read from the point records; 8 instead of 12 bytes per slot and lane lets 20 instead of 13 one-wave blocks share a CU's
+// LDS at k = 15)
 struct KnnList {
     float *d;        // [k][KNN_BLOCK] squared distances, ascending
     uint32_t *j;     // [k][KNN_BLOCK] cell-sorted indices
-    uint32_t *o;     // [k][KNN_BLOCK] original indices
+    const PtF *pts;  // the records the indices refer to (original index in .w)
     int k, cnt, lane;
     __device__ __forceinline__ float &D(int s) { return d[s * KNN_BLOCK + lane]; }
     __device__ __forceinline__ uint32_t &J(int s) { return j[s * KNN_BLOCK + lane]; }
-    __device__ __forceinline__ uint32_t &O(int s) { return o[s * KNN_BLOCK + lane]; }
+    __device__ __forceinline__ uint32_t O(int s) { return pt_orig(pts[j[s * KNN_BLOCK + lane]]); }
 };
 
 __device__ __forceinline__ void knn_offer(KnnList &L, float dist2, uint32_t jj, uint32_t oo, float &kth, uint32_t &kth_o) {
-    if (L.cnt == L.k && !(dist2 < kth || (dist2 == kth && oo < kth_o))) return;
+    // (kth_o holds the cell-sorted INDEX of the current k-th best; its original index is looked up only on an exact tie)
+    if (L.cnt == L.k && !(dist2 < kth || (dist2 == kth && oo < pt_orig(L.pts[kth_o])))) return;
     int p = L.cnt < L.k ? L.cnt : L.k - 1;
     while (p > 0) {
         const float dp = L.D(p - 1);
-        const uint32_t op = L.O(p - 1);
-        if (!(dp > dist2 || (dp == dist2 && op > oo))) break;
-        L.D(p) = dp; L.J(p) = L.J(p - 1); L.O(p) = op;
+        if (!(dp > dist2 || (dp == dist2 && L.O(p - 1) > oo))) break;      // (the original index only on a tie)
+        L.D(p) = dp; L.J(p) = L.J(p - 1);
         --p;
     }
-    L.D(p) = dist2; L.J(p) = jj; L.O(p) = oo;
+    L.D(p) = dist2; L.J(p) = jj;
     if (L.cnt < L.k) ++L.cnt;
-    if (L.cnt == L.k) { kth = L.D(L.k - 1); kth_o = L.O(L.k - 1); }
+    if (L.cnt == L.k) { kth = L.D(L.k - 1); kth_o = L.J(L.k - 1); }
 }
 
 // Candidates are fetched KNN_BATCH at a time (independent loads in flight before the first compare: the search is a chain
@@ -132,7 +135,7 @@ __device__ __forceinline__ KnnList knn_list(int k) {
     L.k = k; L.cnt = 0; L.lane = threadIdx.x;
     L.d = (float *)knn_smem;
     L.j = (uint32_t *)(knn_smem + sizeof(float) * k * KNN_BLOCK);
-    L.o = (uint32_t *)(knn_smem + 2 * sizeof(float) * k * KNN_BLOCK);
+    L.pts = nullptr;
     return L;
 }
 
@@ -141,6 +144,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn_query(Geom<float> g, const Pt
     const int64_t i = (int64_t)blockIdx.x * KNN_BLOCK + threadIdx.x;
     if (i >= m) return;
     KnnList L = knn_list(k);
+    L.pts = pts;
     knn_search(g, pts, cs, q[3 * i], q[3 * i + 1], q[3 * i + 2], L);
     for (int s = 0; s < k; ++s) {
         const bool have = s < L.cnt;
@@ -155,6 +159,7 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn_normals(Geom<float> g, const 
     const int64_t i = (int64_t)blockIdx.x * KNN_BLOCK + threadIdx.x;
     if (i >= n) return;
     KnnList L = knn_list(k);
+    L.pts = pts;
     const PtF me = pts[i];
     knn_search(g, pts, cs, me.x, me.y, me.z, L);
     double c[6];
@@ -213,7 +218,7 @@ extern "C" pcr_status pcr_knn_query(pcr_target *t, const float *q, int64_t m, in
     HIP_TRY(d_dist.alloc((size_t)m * k));
     HIP_TRY(d_idx.alloc((size_t)m * k));
     HIP_TRY(hipMemcpyAsync(d_q.p, q, 12 * (size_t)m, hipMemcpyHostToDevice, ctx->stream));
-    const size_t smem = 3 * sizeof(float) * (size_t)k * KNN_BLOCK;
+    const size_t smem = 2 * sizeof(float) * (size_t)k * KNN_BLOCK;
     hipLaunchKernelGGL(k_knn_query, dim3((unsigned)((m + KNN_BLOCK - 1) / KNN_BLOCK)), dim3(KNN_BLOCK), smem, ctx->stream,
                        t->gf, t->pts, t->cell_start, t->n, (const float *)d_q.p, m, k, d_dist.p, d_idx.p);
     HIP_TRY(hipGetLastError());
@@ -231,7 +236,7 @@ extern "C" pcr_status pcr_target_estimate_normals(pcr_target *t, int k, int comp
     HIP_TRY(hipSetDevice(ctx->device));
     if (!t->pn) HIP_TRY(pcr_persist_alloc((void **)&t->pn, sizeof(PtN) * (size_t)(t->n ? t->n : 1)));
     if (t->n > 0) {
-        const size_t smem = 3 * sizeof(float) * (size_t)k * KNN_BLOCK;
+        const size_t smem = 2 * sizeof(float) * (size_t)k * KNN_BLOCK;
         hipLaunchKernelGGL(k_knn_normals, dim3((unsigned)((t->n + KNN_BLOCK - 1) / KNN_BLOCK)), dim3(KNN_BLOCK), smem,
                            ctx->stream, t->gf, t->pts, t->cell_start, t->n, k, compat, t->pn);
         HIP_TRY(hipGetLastError());

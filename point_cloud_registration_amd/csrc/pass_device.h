@@ -61,7 +61,23 @@ struct LinArgs {
     uint32_t *nn_j;
     uint32_t *tile_ctr;   // tile counters (64 B apart) of the NN kernels' dynamic hand-out
     int sched_local;      // 1: block-local hand-out (small scans), 0: global counters (see nn_tile_loop)
+    // the deeper set of extended lists of a point target (pcr_target::cs_h2 ...; halo2_f = 0: none).  Host-driven passes
+    // put the set they chose into gf; the device-resident loop (pose != NULL) picks per iteration (PoseDev::halo_deep)
+    const uint32_t *cs_h2;
+    const void *pts_h2;
+    const uint32_t *j_h2;
+    float halo2_f;
 };
+
+// the geometry a point search of this launch reads: gf, with the deeper lists swapped in when the device-resident loop
+// asked for them (wave-uniform: a handful of scalar selects at kernel start)
+__device__ __forceinline__ Geom<float> select_lists(const LinArgs &a) {
+    Geom<float> g = a.gf;
+    if (a.pose != nullptr && a.halo2_f > 0.f && __builtin_amdgcn_readfirstlane(a.pose->halo_deep) != 0) {
+        g.halo = a.halo2_f; g.cs_h = a.cs_h2; g.pts_h = a.pts_h2; g.j_h = a.j_h2;
+    }
+    return g;
+}
 
 __device__ __forceinline__ float uniform_f32(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ double uniform_f64(double v) {
@@ -494,7 +510,7 @@ __device__ __forceinline__ void nn_tile_loop(const LinArgs &a, Body &&body) {
 // that moved less than mu since the previous pass searches up to mu beyond its match to make that bound useful;
 // one that moved more searches exactly like the plain kernel (its bound then carries no margin).
 template <int VOXEL, int HALO, int TRACK>
-__device__ __forceinline__ void nn_point(const LinArgs &a, const PoseK &P, const PoseQ &Q, int64_t i) {
+__device__ __forceinline__ void nn_point(const LinArgs &a, const Geom<float> &gf, const PoseK &P, const PoseQ &Q, int64_t i) {
     const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
     float tx, ty, tz;
     xform(P, x, y, z, tx, ty, tz);
@@ -514,10 +530,10 @@ __device__ __forceinline__ void nn_point(const LinArgs &a, const PoseK &P, const
         if (track) {
             NNTrack<float> tk;
             nn_track_init<float>(tk, a.bound2_f, mu);
-            nn_search<float, PtF, false, false, HALO != 0, true>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo, nullptr, &tk);
+            nn_search<float, PtF, false, false, HALO != 0, true>(gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo, nullptr, &tk);
             lb2q = fminf(tk.second, tk.pmin);
         } else {
-            nn_search<float, PtF, false, false, HALO != 0, false>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
+            nn_search<float, PtF, false, false, HALO != 0, false>(gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
             lb2q = best;
         }
         if (TRACK) {
@@ -606,7 +622,11 @@ __device__ __forceinline__ void nn_point_filter(const LinArgs &a, const PoseK &P
     uint32_t w; double d;
     const bool cert = nn_filter_core<HALO, SETTLE, PCR_NN_BATCH>(a, tx, ty, tz, w, d);
     uint32_t out = (w != PCR_NONE && __builtin_sqrt(d) < a.md_d) ? w : PCR_NONE;
+#ifdef PCR_DEV
+    if (!cert && !(a.flags & (2u << 28))) {          // (PCR_FIX_DEBUG=2, timing only: the nominee is taken unchecked)
+#else
     if (!cert) {
+#endif
         out = PCR_PENDING_BIT | w;                   // (cert is only ever false with a nominee: w != PCR_NONE)
         atomicMax(a.pending, a.stamp);
     }
@@ -617,9 +637,10 @@ __device__ __forceinline__ void nn_point_filter(const LinArgs &a, const PoseK &P
 // PCR_PENDING_BIT | index): the exact nearest centroid is the lexicographic minimum of (float64 distance, original index)
 // over the centroids inside the ball through the nominee, which usually touches a handful of cells.  A from-scratch ring
 // search bounded by the gate is a chain of ~50 dependent round trips (two per row of cells: entry, then records) --
-// 50-65 us with the rest of the chip idle, whatever the number of pending points; here the entries of the (at most 3 x 3)
-// rows of the ball's cell box are requested together and the rows scanned with the nominee as the running best:
-// ~5 round trips.  Larger boxes (a nominee near the gate) take the ring search, seeded with the nominee.
+// 50-65 us with the rest of the chip idle, whatever the number of pending points; here the ball's cell box is walked slab
+// by slab, the entries of five rows requested together and the rows scanned with the nominee as the running best.
+// Measured inside k_reduce_finalize<.., FIX> (developer build, PCR_FIX_DEBUG: stream only / + walk of nn_j / + searches):
+// vplane_10m 72 / 83 / 125 us with the ring search for boxes wider than 3 x 3 rows, ndt_10m 100 / 111 / 118 us.
 __device__ __forceinline__ void nn_point_fix(const LinArgs &a, const PoseK &P, int64_t i, uint32_t nominee) {
     float tx, ty, tz;
     xform(P, a.sx[i], a.sy[i], a.sz[i], tx, ty, tz);
@@ -641,21 +662,28 @@ __device__ __forceinline__ void nn_point_fix(const LinArgs &a, const PoseK &P, i
     const int xl = cell(qx - r, g.ox, g.nx), xh = cell(qx + r, g.ox, g.nx);
     const int yl = cell(qy - r, g.oy, g.ny), yh = cell(qy + r, g.oy, g.ny);
     const int zl = cell(qz - r, g.oz, g.nz), zh = cell(qz + r, g.oz, g.nz);
-    if (yh - yl <= 2 && zh - zl <= 2) {
-        const uint32_t unx = (uint32_t)g.nx, plane = (uint32_t)g.ny * unx;
-        uint32_t s_[9], e_[9];
+    // slabs of the box in z, rows five at a time: their ten entries are requested together (one round trip), then the rows are
+    // scanned with the running best; a slab or row that lies beyond the best is skipped (the ball only shrinks)
+    const uint32_t unx = (uint32_t)g.nx, plane = (uint32_t)g.ny * unx;
+    for (int z = zl; z <= zh; ++z) {
+        const double zlo_ = g.oz + (double)z * g.h;
+        const double dzm = fmax(fmax(zlo_ - qz, qz - (zlo_ + g.h)) - g.slack, 0.0);
+        if (dzm * dzm > bd) continue;
+        for (int y0 = yl; y0 <= yh; y0 += 5) {
+            uint32_t s_[5], e_[5];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {                                 // all entries in flight at once
-            const int y = yl + k % 3, z = zl + k / 3;
-            const bool live = y <= yh && z <= zh;
-            const uint32_t row = (uint32_t)(live ? z : zl) * plane + (uint32_t)(live ? y : yl) * unx;
-            const uint32_t s0 = a.cell_start[row + (uint32_t)xl] & g.cs_mask, e0 = a.cell_start[row + (uint32_t)xh + 1u] & g.cs_mask;
-            s_[k] = s0; e_[k] = live ? e0 : s0;
+            for (int k = 0; k < 5; ++k) {
+                const int y = y0 + k;
+                const double ylo_ = g.oy + (double)y * g.h;
+                const double dym = fmax(fmax(ylo_ - qy, qy - (ylo_ + g.h)) - g.slack, 0.0);
+                const bool live = y <= yh && dzm * dzm + dym * dym <= bd;
+                const uint32_t row = (uint32_t)z * plane + (uint32_t)(live ? y : yl) * unx;
+                const uint32_t s0 = a.cell_start[row + (uint32_t)xl] & g.cs_mask, e0 = a.cell_start[row + (uint32_t)xh + 1u] & g.cs_mask;
+                s_[k] = s0; e_[k] = live ? e0 : s0;
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) nn_scan_range<double, PtD, 0>(a.means, s_[k], e_[k], qx, qy, qz, bd, bj, bo);
         }
-#pragma unroll
-        for (int k = 0; k < 9; ++k) nn_scan_range<double, PtD, 0>(a.means, s_[k], e_[k], qx, qy, qz, bd, bj, bo);
-    } else {
-        nn_search<double, PtD, false, true, false, 0, false>(g, a.means, a.cell_start, qx, qy, qz, bd * 1.0000001, bd, bj, bo);
     }
     a.nn_j[i] = __builtin_sqrt(bd) < a.md_d ? bj : PCR_NONE;
 }
@@ -680,6 +708,7 @@ struct FinArgs {
     // bounding box of the scan and the displacement below which the next search deals its tiles block-locally
     float bb_c[3], bb_e[3];
     double local_len;
+    double deep_len;           // ... and the displacement from which on it reads the deeper set of extended lists
     // device-resident Gauss-Newton loop (pcr_align; registration.py:89-111 behind the boundary)
     PoseDev *pose;             // NULL: plain pass
     int max_iter;

@@ -63,6 +63,9 @@ struct Geom {
     const unsigned long long *rowocc;
     int nyw, nxb;
 };
+#define PCR_HALO2_FRAC 0.25      // margin of the deeper list set, x cell
+#define PCR_HALO2_AFTER 12       // passes a point target serves before the deeper set is built (~0.3 ms: repaid after ~60 passes)
+#define PCR_HALO2_MOVE 0.12      // the deeper set serves passes whose scan moved by at least this x cell since the previous pass
 #define PCR_GAP_SHIFT 28
 #define PCR_GAP_MAX 15
 
@@ -88,6 +91,7 @@ struct PoseDev {
     int iter;              // passes completed
     int done;              // 0 running, 1 converged, 2 singular, 3 max_iter reached
     int tile_local;        // hand-out policy of the next search, decided by k_gn_update from the size of its step
+    int halo_deep;         // the next search reads the deeper set of extended lists (the step was large), same decision point
 };
 #define PCR_LOOP_RUNNING 0
 #define PCR_LOOP_CONVERGED 1
@@ -250,6 +254,16 @@ struct pcr_target {
     PtF *pts_h = nullptr;
     uint32_t *j_h = nullptr;
     int64_t n_h = 0;                 // records in pts_h
+    // a second, deeper set of the same lists (halo PCR_HALO2_FRAC x cell), built lazily once the target has served
+    // PCR_HALO2_AFTER search + reduce passes; a pass reads it while the scan still moves by more than PCR_HALO2_MOVE x cell
+    // per pass (measured per pose on plane_b01, halo 0.1 / 0.25: 232 / 232, 180 / 180, 105 / 89, 49 / 40, 32 / 39 us)
+    uint32_t *cs_h2 = nullptr;
+    PtF *pts_h2 = nullptr;
+    uint32_t *j_h2 = nullptr;
+    int64_t n_h2 = 0;
+    float halo2 = 0;
+    int split_passes = 0;            // search + reduce passes served (point targets)
+    bool deep_tried = false;
     // point targets
     Geom<float> gf;
     PtF *pts = nullptr;        // cell-sorted (the NN search reads these 16-byte records)
@@ -319,8 +333,10 @@ void pcr_target_release(pcr_target *t);      // frees a target and everything it
 // ---- index_build.hip
 pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n, float cell_hint, pcr_target *t, bool use_env = true);
 pcr_status pcr_build_centroid_filter(pcr_context *ctx, pcr_target *t);
+pcr_status pcr_build_deep_lists(pcr_context *ctx, pcr_target *t);
 pcr_status pcr_build_centroid_grid(pcr_context *ctx, const double *d_mean, int64_t n, double cell, pcr_target *t);
-pcr_status pcr_count_nonfinite(pcr_context *ctx, const void *d_xyz, int is_f64, int64_t n, int64_t *count);
+pcr_status pcr_count_nonfinite(pcr_context *ctx, const void *d_xyz, int is_f64, int64_t n, int64_t *count, float *lo_out = nullptr,
+                               float *hi_out = nullptr);     // (+ the bounding box of the finite points, rounded to float32)
 pcr_status pcr_sort_scan(pcr_context *ctx, const float *d_xyz, int64_t n, unsigned flags, pcr_scan *s);
 pcr_status pcr_permute_normals(pcr_context *ctx, const float *d_in, int64_t n, const PtF *pts, PtN *out);
 pcr_status pcr_permute_rows_f64(pcr_context *ctx, const double *d_in, int64_t n, int in_stride, const int *cols,

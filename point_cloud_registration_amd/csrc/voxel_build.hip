@@ -21,8 +21,9 @@ __device__ __forceinline__ long long pymod(long long a, long long m) {
     return r < 0 ? r + m : r;
 }
 
+// (bias: added to every key so that the radix sort only has to look at the bits keys actually use -- see voxel_build)
 template <typename T>
-__global__ void __launch_bounds__(256) k_voxel_keys(const T *__restrict__ xyz, int64_t n, T voxel_size,
+__global__ void __launch_bounds__(256) k_voxel_keys(const T *__restrict__ xyz, int64_t n, T voxel_size, long long bias,
                                                     long long *keys, uint32_t *idx) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -31,7 +32,7 @@ __global__ void __launch_bounds__(256) k_voxel_keys(const T *__restrict__ xyz, i
     const long long x = (long long)floor(xyz[3 * i] / voxel_size);
     const long long y = (long long)floor(xyz[3 * i + 1] / voxel_size);
     const long long z = (long long)floor(xyz[3 * i + 2] / voxel_size);
-    keys[i] = pymod((pymod(z * P, M) + y) * P, M) + x;                            // voxel.py:20
+    keys[i] = pymod((pymod(z * P, M) + y) * P, M) + x + bias;                     // voxel.py:20
     idx[i] = (uint32_t)i;
 }
 
@@ -54,7 +55,7 @@ __global__ void __launch_bounds__(256) k_voxel_stats(const T *__restrict__ xyz, 
                                                      const uint32_t *__restrict__ counts,
                                                      const uint32_t *__restrict__ seg_start,
                                                      const uint32_t *__restrict__ keep_pos, int64_t nu, int min_points,
-                                                     double *mean, double *cov, double *norm, double *icov,
+                                                     long long key_bias, double *mean, double *cov, double *norm, double *icov,
                                                      int64_t *out_counts, int64_t *out_keys) {
     __shared__ double buf[4][3][VS_CHUNK];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -111,12 +112,12 @@ __global__ void __launch_bounds__(256) k_voxel_stats(const T *__restrict__ xyz, 
 #pragma unroll
     for (int a = 0; a < 9; ++a) icov[9 * (size_t)o + a] = ic[a];
     out_counts[o] = (int64_t)cnt;
-    out_keys[o] = ukeys[v];
+    out_keys[o] = ukeys[v] - key_bias;
 }
 
 template <typename T>
 static pcr_status voxel_build(pcr_context *ctx, const T *d_xyz, int64_t n, double voxel_size, int min_points,
-                              pcr_target *t) {
+                              pcr_target *t, float x_lo, float x_hi) {
     const size_t nn = (size_t)(n > 0 ? n : 1);
     const unsigned nb = (unsigned)((n + 255) / 256);
     // temporaries: blocks of the context's cache (DevBuf), gone on every exit path
@@ -129,12 +130,31 @@ static pcr_status voxel_build(pcr_context *ctx, const T *d_xyz, int64_t n, doubl
     HIP_TRY(i1.alloc(nn)); HIP_TRY(i2.alloc(nn));
     HIP_TRY(counts.alloc(nn + 1)); HIP_TRY(seg.alloc(nn + 1)); HIP_TRY(flags.alloc(nn + 1));
     HIP_TRY(d_runs.alloc(1));
+    // A key is (a residue in [0, 1e10)) + x with x = floor(px / voxel_size): adding bias = -min(x, 0) makes every key
+    // non-negative and smaller than 1e10 + (x_max - x_min), i.e. ~34 significant bits for any real cloud, and a stable radix
+    // sort of those bits orders them exactly as a sort of all 64 does: 5 onesweep passes instead of 8 (25 us each per 1.06 M
+    // points).  The x range comes from the bounding box (float32-rounded: a margin of 2 voxels + 1e-6 relative covers it);
+    // coordinates beyond what 60 bits hold keep the full sort.
+    long long key_bias = 0;
+    int key_bits = 64;
+    {
+        const double xl = floor((double)x_lo / voxel_size), xh = floor((double)x_hi / voxel_size);
+        const double xmin = xl - 2.0 - 1e-6 * fabs(xl), xmax = xh + 2.0 + 1e-6 * fabs(xh);
+        if (std::isfinite(xmin) && std::isfinite(xmax) && fabs(xmin) < 1e17 && fabs(xmax) < 1e17) {
+            key_bias = xmin < 0 ? (long long)(-xmin) : 0;
+            const double top = 1.0e10 + xmax + (double)key_bias;
+            int b = 1;
+            while (b < 62 && ldexp(1.0, b) <= top) ++b;
+            key_bits = b < 62 ? b : 64;
+            if (key_bits == 64) key_bias = 0;
+        }
+    }
     if (n > 0) {
-        hipLaunchKernelGGL(k_voxel_keys<T>, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, (T)voxel_size, k1.p, i1.p);
+        hipLaunchKernelGGL(k_voxel_keys<T>, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, (T)voxel_size, key_bias, k1.p, i1.p);
         size_t tb = 0;
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k1.p, k2.p, i1.p, i2.p, (int)n, 0, 64, ctx->stream));
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k1.p, k2.p, i1.p, i2.p, (int)n, 0, key_bits, ctx->stream));
         HIP_TRY(tmp.alloc_bytes(tb));
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k1.p, k2.p, i1.p, i2.p, (int)n, 0, 64, ctx->stream));
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, k1.p, k2.p, i1.p, i2.p, (int)n, 0, key_bits, ctx->stream));
         tb = 0;
         HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb, k2.p, ukeys.p, counts.p, d_runs.p, (int)n, ctx->stream));
         DevBuf<char> tmp2;
@@ -165,7 +185,7 @@ static pcr_status voxel_build(pcr_context *ctx, const T *d_xyz, int64_t n, doubl
         HIP_TRY(pcr_persist_alloc((void **)&t->st_counts, 8 * kk)); HIP_TRY(pcr_persist_alloc((void **)&t->st_keys, 8 * kk));
         if (nu > 0) {
             hipLaunchKernelGGL(k_voxel_stats<T>, dim3((unsigned)((nu + 3) / 4)), dim3(256), 0, ctx->stream, d_xyz, i2.p,
-                               ukeys.p, counts.p, seg.p, flags.p, nu, min_points, t->st_mean, t->st_cov, t->st_norm, t->st_icov,
+                               ukeys.p, counts.p, seg.p, flags.p, nu, min_points, key_bias, t->st_mean, t->st_cov, t->st_norm, t->st_icov,
                                t->st_counts, t->st_keys);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -191,15 +211,16 @@ extern "C" pcr_status pcr_target_voxels_create(pcr_context *ctx, const void *xyz
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     int64_t nonfinite = 0;
-    PCR_TRY(pcr_count_nonfinite(ctx, d_xyz.p, xyz_is_f64, n, &nonfinite));
+    float lo[3], hi[3];
+    PCR_TRY(pcr_count_nonfinite(ctx, d_xyz.p, xyz_is_f64, n, &nonfinite, lo, hi));
     if (nonfinite > 0) {               // floor(NaN / voxel_size).astype(int64) is undefined in the reference as well
         pcr_set_error("cloud has %lld point(s) with a non-finite coordinate; drop them first", (long long)nonfinite);
         return PCR_ERR_INVALID;
     }
     pcr_target *t = new pcr_target();
     t->ctx = ctx; t->is_voxel = 1; t->serial = ctx->next_serial++;
-    pcr_status s = xyz_is_f64 ? voxel_build<double>(ctx, (const double *)d_xyz.p, n, voxel_size, min_points, t)
-                              : voxel_build<float>(ctx, (const float *)d_xyz.p, n, voxel_size, min_points, t);
+    pcr_status s = xyz_is_f64 ? voxel_build<double>(ctx, (const double *)d_xyz.p, n, voxel_size, min_points, t, lo[0], hi[0])
+                              : voxel_build<float>(ctx, (const float *)d_xyz.p, n, voxel_size, min_points, t, lo[0], hi[0]);
     d_xyz.reset();
     if (s != PCR_OK) { pcr_target_destroy(t); return s; }
     *out = t;

@@ -38,7 +38,7 @@ def test_developer_pipelines_in_the_developer_build():
     from point_cloud_registration_amd import _capi
     assert os.path.exists(_capi.DEV_LIB_PATH), "make dev (csrc/Makefile) builds libpcr_hip_dev.so"
     env = dict(os.environ, PCR_LIB=_capi.DEV_LIB_PATH)
-    expr = " or ".join(DEV_PIPELINES) + " or nn_counters"
+    expr = " or ".join(DEV_PIPELINES) + " or nn_counters or fuzz_against_oracle"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(REPO, "tests", "test_gpu_parity.py"),
                         os.path.join(REPO, "tests", "test_reference_style.py"), os.path.join(REPO, "tests", "test_gpu_dev_build.py"),
                         "-m", "gpu", "-x", "-q", "-k", expr, "-p", "no:cacheprovider"],

@@ -696,7 +696,7 @@ def _fuzz_cloud(rng, n):
 def test_fuzz_against_oracle(capi, orc, ctx, seed):
     """Random cloud family / size / scale / offset / pose / gate / kind / kernel pipeline: correspondences
     bit-exact against brute force, the 29 sums against the oracle."""
-    from conftest import PIPELINES
+    from conftest import PIPELINES, DEV_PIPELINES
     from point_cloud_registration_amd.math_tools import makeT, expSO3
     rng = np.random.default_rng(1000 + seed)
     n_t = int(rng.choice([1, 2, 17, 300, 4000, 30000]))
@@ -715,6 +715,10 @@ def test_fuzz_against_oracle(capi, orc, ctx, seed):
     assert np.array_equal(i, io) and np.array_equal(d, do)
     # the pass, every kind that this cloud supports, on a random kernel pipeline
     name = list(PIPELINES)[int(rng.integers(0, len(PIPELINES)))]
+    if name in DEV_PIPELINES and not capi.has_dev_kernels():
+        # (the developer pipelines run where the developer kernels are: tests/test_gpu_dev_build.py re-runs this test in a
+        # process that loaded libpcr_hip_dev.so; the shipped library takes the shipped counterpart)
+        name = {"coop": "split", "unfused": "reuse", "onekernel_unfused": "onekernel"}[name]
     normals = rng.normal(size=target.shape).astype(np.float32)
     normals /= np.linalg.norm(normals, axis=1, keepdims=True)
     o_pts = orc.TargetPoints(target, normals=normals)
@@ -930,6 +934,48 @@ def test_certified_reuse_shared_point_target(capi, ctx):
         g2_ = capi.linearize(tgt2, s1, capi.ICP, poses[-1], 2.0)
         assert s1.reuse_stats()["last_mode"] == capi.NN_FULL
     assert np.array_equal(r2, g2_)
+
+
+def test_deeper_list_set_is_exact(capi, orc, ctx):
+    """A point target that has served a dozen search + reduce passes gets a second, deeper set of extended lists (halo
+    0.25 cell); passes whose scan moved far since the previous one (or that have no history) read it, the others the
+    first set -- per launch for host-driven passes, per iteration (k_gn_update) in the device-resident loop.  Whatever
+    is picked, matches and sums must be those of a FRESH target (first set only) and of the oracle."""
+    from point_cloud_registration_amd.synthetic import street, perturbed_scan, make_T
+    target = street(200_000, seed=31)
+    scan, T_true = perturbed_scan(target, None, seed=32)
+    normals = capi.Target.points(ctx, target).estimate_normals(15)     # (real normals: constant ones leave H singular)
+    warm = capi.Target.points(ctx, target, normals)
+    sc = capi.Scan(ctx, scan)
+    rng = np.random.default_rng(5)
+    with ctx.pipeline(variant=1, reuse=0):
+        for _ in range(14):                                   # the passes that earn the deeper lists
+            capi.linearize(warm, sc, capi.PLANE, np.eye(4), 2.0)
+    info = warm.index_info()
+    assert info["halo2_records"] > info["halo_records"] > 0 and abs(info["halo2"] - 0.25 * info["cell"]) < 1e-6
+    poses = [np.eye(4), T_true]
+    T = np.eye(4)
+    for step in (0.3, 0.3, 0.1, 0.04, 0.01, 0.003, 0.2, 0.0005, 0.0005):      # large and small displacements in turn
+        T = T @ make_T(rng.normal(0, 0.02 * step, 3), rng.normal(0, step, 3))
+        poses.append(T.copy())
+    ot = orc.TargetPoints(target, normals=normals)
+    for k, T in enumerate(poses):
+        fresh = capi.Target.points(ctx, target, normals)
+        sc_f = capi.Scan(ctx, scan)
+        with ctx.pipeline(variant=1, reuse=0):
+            a = capi.linearize(warm, sc, capi.PLANE, T, 2.0).copy(); ma = sc.matches()
+            b = capi.linearize(fresh, sc_f, capi.PLANE, T, 2.0).copy(); mb = sc_f.matches()
+        assert np.array_equal(ma, mb) and np.array_equal(a, b), k
+        if k in (0, 1, 4, 9):
+            Ho, go, e2o, cnto = orc.calc_H_g_e2(orc.PLANE, ot, T, scan, 2.0, with_count=True)
+            H, g, e2, cnt = capi.unpack29(a)
+            assert cnt == cnto and rel_H(H, Ho) < 1e-9
+    # the device-resident loop picks per iteration: same pose, same iteration count, bit for bit
+    fresh = capi.Target.points(ctx, target, normals)
+    for kind in (capi.ICP, capi.PLANE):
+        T1, it1 = capi.align(warm, sc, kind, np.eye(4), 30, 1e-3, 2.0, flags=capi.FLAG_ICP_RR_QUIRK | capi.FLAG_DEVICE_LOOP)
+        T2, it2 = capi.align(fresh, capi.Scan(ctx, scan), kind, np.eye(4), 30, 1e-3, 2.0, flags=capi.FLAG_ICP_RR_QUIRK | capi.FLAG_DEVICE_LOOP)
+        assert it1 == it2 and np.array_equal(T1, T2)
 
 
 def test_quirk_q6_float64_target(capi, g9):

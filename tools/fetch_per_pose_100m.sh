@@ -8,7 +8,8 @@ runp() { local pose=$1; shift
   timeout -k 5 600 rocprofv3 --pmc "$@" --kernel-trace --output-format rocpd -d "$out/prof_pp" -o r -- python $root/tools/pose0_passes.py $pose 100m > "$out/prof_pp.log" 2>&1
   local db=$(find "$out/prof_pp" -name "*.db" | head -1)
   echo "== pose $pose ($*)" >> $res
-  python "$root/tools/rocpd_summary.py" "$db" 2>&1 | grep -E "k_nn_scan|k_reduce_fin" >> $res
+  python "$root/tools/rocpd_last.py" "$db" k_nn_scan 40 >> $res 2>&1
+  python "$root/tools/rocpd_last.py" "$db" k_reduce_finalize 40 >> $res 2>&1
   rm -rf "$out/prof_pp"; }
 for pose in ${1:-0 5 12 20 25}; do
   runp $pose FETCH_SIZE

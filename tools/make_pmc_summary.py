@@ -9,7 +9,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import bench
 
-HOT = ("k_nn_scan", "k_certify", "k_nn_coop", "k_reduce_finalize", "k_reduce", "k_linearize", "k_finalize", "k_gn_update")
+HOT = ("k_nn_scan", "k_nn_filter", "k_nn_fix", "k_certify", "k_nn_coop", "k_reduce_finalize", "k_reduce", "k_linearize", "k_finalize", "k_gn_update")
+ROUND = os.environ.get("PCR_PROFILE_ROUND", "r04")
 
 
 def parse(path, counter):
@@ -27,7 +28,9 @@ def parse(path, counter):
 def main():
     commit = subprocess.run(["git", "-C", REPO, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
     summary = {"_comment": __doc__.replace("\n", " "), "kernel_source_hash": bench.kernel_source_hash(), "commit": commit}
-    for cfg, tag in (("plane_b01", "r03_plane_b01"), ("plane_100m", "r03_plane_100m"), ("icp_b01_harness", "r03_icp_b01_harness")):
+    for cfg in ("plane_b01", "icp_b01", "icp_b01_harness", "plane_b01_100k", "vplane_b01_harness", "ndt_b01_harness", "vplane_10m", "ndt_10m",
+                "plane_100m", "plane_b01_resampled"):
+        tag = f"{ROUND}_{cfg}"
         f = parse(os.path.join(REPO, "profiles", tag + "_pmc_fetch.txt"), "FETCH_SIZE")
         w = parse(os.path.join(REPO, "profiles", tag + "_pmc_write.txt"), "WRITE_SIZE")
         if not f:
