@@ -60,6 +60,28 @@ PCR_HD static inline int gn_solve6(double (*A)[7], const double H[36], const dou
     return 0;
 }
 
+// sin and cos of one angle from ONE piece of code for host and device (round 4).  libm's and the device library's sin / cos
+// may differ in the last bit, and the full Rodrigues branch below then makes the host-driven and the device-resident loop
+// part ways after a large step (found by tools/soak.py on a one-voxel target: 24 correspondences, an ill-conditioned H, a
+// 0.3 rad step).  Cody-Waite reduction by pi/2 (three-part constant) + the fdlibm kernel polynomials, plain multiplies and
+// adds (the TUs are compiled with -ffp-contract=off): within ~1 ulp of libm, identical wherever it is compiled.
+PCR_HD static inline void gn_sincos(double x, double *sn, double *cs) {
+    const double k = floor(x * 6.36619772367581382433e-01 + 0.5);            // x * 2/pi, nearest
+    double r = x - k * 1.57079632673412561417e+00;                             // pi/2 in three parts (33 + 33 + 53 bits)
+    r = r - k * 6.07710050630396597660e-11;
+    r = r - k * 2.02226624871116645580e-21;
+    const double z = r * r;
+    const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                      z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+    const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    const double s0 = r + r * z * ps;
+    const double c0 = (1.0 - 0.5 * z) + z * z * pc;
+    const int q = (int)(k - 4.0 * floor(k * 0.25));                            // k mod 4 (k >= 0 here, fine for k < 0 too)
+    *sn = q == 0 ? s0 : (q == 1 ? c0 : (q == 2 ? -s0 : -c0));
+    *cs = q == 0 ? c0 : (q == 1 ? -s0 : (q == 2 ? -c0 : s0));
+}
+
 // math_tools.py:80-98: first-order I + skew(w) when w.w <= 1e-5 (quirk Q3), Rodrigues otherwise
 PCR_HD static inline void gn_exp_so3(const double w[3], double R[9]) {
     const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
@@ -67,7 +89,10 @@ PCR_HD static inline void gn_exp_so3(const double w[3], double R[9]) {
     if (th2 <= 1e-5) {
         for (int i = 0; i < 9; ++i) R[i] = W[i];
     } else {
-        const double th = sqrt(th2), sn = sin(th), omc = 1.0 - cos(th);
+        const double th = sqrt(th2);
+        double sn, cth;
+        gn_sincos(th, &sn, &cth);
+        const double omc = 1.0 - cth;
         double K[9];
         for (int i = 0; i < 9; ++i) K[i] = W[i] / th;
         for (int i = 0; i < 3; ++i)

@@ -592,6 +592,8 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
         t->filter_tried = true;
         // a failed build (out of memory, say) must not fail the pass: the float64 search needs no filter
         if (pcr_build_centroid_filter(ctx, t) != PCR_OK || (t->filter && !(t->filter_band > 0))) {
+            fprintf(stderr, "[pcr] the float32 filter index of a voxel target could not be built (%s); its centroid searches stay in float64\n",
+                    pcr_last_error());
             (void)hipGetLastError();
             pcr_target_release(t->filter);
             t->filter = nullptr; t->filter_band = 0;

@@ -1056,6 +1056,83 @@ def test_centroid_filter_is_exact(capi, orc, ctx, vs, offset):
         assert rel_H(H, Ho) < 1e-9
 
 
+def test_fused_kernel_filter_is_exact(capi, orc, ctx):
+    """The fused small-scan kernel searches centroids through the float32 filter with two-way settling once a voxel target
+    has served 8 fused passes (`linearize_body<KIND, HALO, FILT>`): the pass before the filter index exists (float64
+    search) and the passes after it must give the same 29 sums bit for bit, equal to the split pipelines with and without
+    the filter; duplicated centroids (exact ties, settled by the original index) and queries ON centroids / between two of
+    them included; the oracle on the un-duplicated target."""
+    from point_cloud_registration_amd.synthetic import street, perturbed_scan, make_T
+    rng = np.random.default_rng(77)
+    target = street(300_000, seed=41)
+    full, _ = perturbed_scan(target, None, seed=42)
+    o_vox = orc.TargetVoxels(target, 1.0)
+    for trial in range(6):
+        dup = trial % 2 == 1
+        mean, norm, icov = o_vox.mean, o_vox.norm, o_vox.icov
+        if dup:                                           # every 7th centroid again at the end: exact two-way ties
+            mean = np.concatenate([mean, mean[::7]]); norm = np.concatenate([norm, norm[::7]]); icov = np.concatenate([icov, icov[::7]])
+        n = int(rng.choice([700, 2049, 30_000, 131_072]))
+        src = full[rng.permutation(len(full))[:n]]
+        on = o_vox.mean[rng.integers(0, len(o_vox.mean), 300)].astype(np.float32)
+        mid = (0.5 * (o_vox.mean[:300] + o_vox.mean[1:301])).astype(np.float32)
+        src = np.ascontiguousarray(np.concatenate([src, on, mid]), dtype=np.float32)
+        T = make_T(rng.normal(0, 0.01, 3), rng.normal(0, 0.05, 3)) if trial else np.eye(4)
+        for kind, okind in ((capi.VPLANE, orc.VPLANE), (capi.NDT, orc.NDT)):
+            tv = capi.Target.voxels_from_stats(ctx, mean, norm, icov, 1.0)
+            sc = capi.Scan(ctx, src)
+            a = capi.linearize(tv, sc, kind, T, 2.0).copy()              # fused kernel, float64 search: no filter index yet
+            assert tv.index_info()["filter_band"] == 0
+            for _ in range(9):
+                capi.linearize(tv, sc, kind, T, 2.0)
+            assert tv.index_info()["filter_band"] > 0                    # built by the 9th fused pass
+            b = capi.linearize(tv, sc, kind, T, 2.0).copy()              # fused kernel, filter + settling
+            with ctx.pipeline(variant=1, nn_mode=3, reuse=0):
+                c = capi.linearize(tv, sc, kind, T, 2.0).copy()          # search + reduce, float64 only
+            with ctx.pipeline(variant=1, nn_mode=0, reuse=0):
+                d = capi.linearize(tv, sc, kind, T, 2.0).copy()          # search + reduce, filter + prologue
+            assert np.array_equal(a, b), (trial, kind, a[28], b[28])
+            assert np.array_equal(c, d) and a[28] == c[28], (trial, kind)
+            assert np.allclose(a, c, rtol=1e-11, atol=1e-9 * np.max(np.abs(c)))     # (another summation order)
+            if not dup:
+                Ho, go, e2o, cnto = orc.calc_H_g_e2(okind, o_vox, T, src, 2.0, with_count=True)
+                H, g, e2, cnt = capi.unpack29(b)
+                assert cnt == cnto and rel_H(H, Ho) < 1e-9
+            # device-resident loop == host-driven loop, bit for bit, on the filter path (also after a LARGE step: gn_sincos)
+            try:
+                Td, itd = capi.align(tv, sc, kind, T, 8, 1e-3, 2.0, capi.FLAG_ICP_RR_QUIRK | capi.FLAG_DEVICE_LOOP)
+                Th, ith = capi.align(tv, sc, kind, T, 8, 1e-3, 2.0, capi.FLAG_ICP_RR_QUIRK | capi.FLAG_HOST_LOOP)
+                assert itd == ith and np.array_equal(Td, Th), (trial, kind)
+            except np.linalg.LinAlgError:
+                pass
+
+
+def test_loops_agree_after_a_large_step(capi, ctx):
+    """tools/soak.py (round 4): a one-voxel target, 24 correspondences, an ill-conditioned H and a 0.3 rad Gauss-Newton
+    step -- the full Rodrigues branch of expSO3, where libm's and the device library's sin / cos differed in the last bit
+    and the host-driven and device-resident loops parted ways.  Both now run gn_sincos (csrc/gn_math.h)."""
+    rng = np.random.default_rng(3)
+    blob = rng.normal(0, 0.15, (40, 3)).astype(np.float64) + np.array([5.0, 3.0, 1.0])
+    tv = capi.Target.voxels(ctx, blob, 1.0, 10)
+    assert tv.size() >= 1
+    src = (blob[:24] + rng.normal(0, 0.05, (24, 3))).astype(np.float32)
+    for n_rep in (1, 1200):                       # 24 points (fused kernel) and the same cloud repeated (larger grid)
+        sc = capi.Scan(ctx, np.ascontiguousarray(np.tile(src, (n_rep, 1))))
+        for kind in (capi.VPLANE, capi.NDT):
+            for T in (np.eye(4), _far_pose()):
+                try:
+                    Td, itd, trd = capi.align(tv, sc, kind, T, 10, 1e-3, 2.0, capi.FLAG_ICP_RR_QUIRK | capi.FLAG_DEVICE_LOOP, want_trace=True)
+                    Th, ith, trh = capi.align(tv, sc, kind, T, 10, 1e-3, 2.0, capi.FLAG_ICP_RR_QUIRK | capi.FLAG_HOST_LOOP, want_trace=True)
+                except np.linalg.LinAlgError:
+                    continue
+                assert itd == ith and np.array_equal(trd, trh) and np.array_equal(Td, Th), (n_rep, kind)
+
+
+def _far_pose():
+    from point_cloud_registration_amd.synthetic import make_T
+    return make_T([0.2, -0.15, 0.1], [0.05, -0.02, 0.03])
+
+
 def test_centroid_filter_everything_pending(capi, orc, ctx):
     """EVERY centroid duplicated: every matched point is an exact tie the float32 filter cannot certify, so k_nn_fix
     searches all 1.3 M of them in float64; then a small scan, then the large one again (the stamps of consecutive passes).

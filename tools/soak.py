@@ -54,6 +54,16 @@ while time.time() - t0 < seconds:
             except np.linalg.LinAlgError:
                 Th, ith = None, None
             if Th is not None and (itd != ith or not np.array_equal(Td, Th)):
-                print("LOOP MISMATCH", n, kind, itd, ith); sys.exit(1)
+                print("LOOP MISMATCH", n, kind, itd, ith, "index", tgt.index_info())
+                # diagnostics: the two loops again with their traces -- where do the sums part?
+                Td2, itd2, trd = _capi.align(tgt, sc, kind, T, 10, 1e-3, 2.0, _capi.FLAG_ICP_RR_QUIRK | _capi.FLAG_DEVICE_LOOP, want_trace=True)
+                Th2, ith2, trh = _capi.align(tgt, sc, kind, T, 10, 1e-3, 2.0, _capi.FLAG_ICP_RR_QUIRK | _capi.FLAG_HOST_LOOP, want_trace=True)
+                print("  again: equal now?", np.array_equal(Td2, Th2), "device run reproducible?", np.array_equal(Td, Td2), "host run reproducible?", np.array_equal(Th, Th2))
+                for k in range(min(itd2, ith2)):
+                    if not np.array_equal(trd[k], trh[k]):
+                        print("  first differing iteration", k, "pose equal", np.array_equal(trd[k, :16], trh[k, :16]), "count", trd[k, 44], trh[k, 44],
+                              "max rel diff of the sums", np.max(np.abs(trd[k, 16:] - trh[k, 16:])) / np.max(np.abs(trh[k, 16:])))
+                        break
+                sys.exit(1)
     sc.close()
 print(f"soak ok: {passes} passes over {scans} scans, {rebuilds} target rebuilds in {time.time() - t0:.1f} s")
