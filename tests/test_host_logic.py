@@ -308,6 +308,57 @@ int main() {
     assert [int(v) for v in out[1:]] == want
 
 
+def test_gn_math_se3_against_the_reference_golden(g5):
+    """csrc/gn_math.h compiled as plain host C++ (what api.hip's host loop and k_gn_update's device code share): expSO3 / plus
+    against the REFERENCE's outputs of fixture g5 (math_tools.py:80-108, either side of the first-order branch, quirk Q3), and
+    gn_sincos -- the one sin / cos both loops use since round 4 -- against libm over six decades of angles."""
+    import os
+    import subprocess
+    import tempfile
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = g5["omegas"].shape[0]
+    rows = ",".join("{" + ",".join(repr(float(v)) for v in w) + "}" for w in g5["omegas"])
+    dxs = ",".join("{" + ",".join(repr(float(v)) for v in w) + "}" for w in g5["dxs"])
+    t0 = ",".join(repr(float(v)) for v in g5["T0"].reshape(16))
+    src = r"""
+#include <stdio.h>
+#include <math.h>
+#include "gn_math.h"
+int main() {
+    const double om[][3] = {%s};
+    const double dx[][6] = {%s};
+    const double T0[16] = {%s};
+    for (int i = 0; i < %d; ++i) {
+        double R[9]; gn_exp_so3(om[i], R);
+        for (int k = 0; k < 9; ++k) printf("%%.17g ", R[k]);
+        double T[16]; for (int k = 0; k < 16; ++k) T[k] = T0[k];
+        gn_se3_plus(T, dx[i]);
+        for (int k = 0; k < 16; ++k) printf("%%.17g ", T[k]);
+        printf("\n");
+    }
+    double ws = 0, wc = 0;
+    for (int i = 0; i < 400000; ++i) {
+        const double x = 1e-3 * pow(1.00004, i);            /* 1e-3 .. 9e3 rad */
+        double s, c; gn_sincos(x, &s, &c);
+        ws = fmax(ws, fabs(s - sin(x))); wc = fmax(wc, fabs(c - cos(x)));
+    }
+    printf("%%.3e %%.3e\n", ws, wc);
+    return 0;
+}
+""" % (rows, dxs, t0, n)
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.cpp"), "w").write(src)
+        subprocess.run(["g++", "-O2", "-ffp-contract=off", "-I", os.path.join(repo, "point_cloud_registration_amd", "csrc"),
+                        os.path.join(d, "t.cpp"), "-o", os.path.join(d, "t")], check=True, capture_output=True)
+        out = subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    for i in range(n):
+        v = np.array([float(x) for x in out[i].split()])
+        assert np.max(np.abs(v[:9].reshape(3, 3) - g5["Rs"][i])) < 1e-14, i
+        assert np.max(np.abs(v[9:].reshape(4, 4) - g5["Ts"][i])) < 1e-13, i
+    ws, wc = (float(x) for x in out[n].split())
+    assert ws < 1e-12 and wc < 1e-12, (ws, wc)           # (~1 ulp below a few rad; the reduction loses digits at 1e3 rad)
+
+
 def _filter_consts(maxabs, bound):
     """gn_filter_band / gn_filter_bounds (csrc/gn_math.h) through g++: the numbers the library computes."""
     import os

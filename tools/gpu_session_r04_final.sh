@@ -34,6 +34,7 @@ tools/collect_profiles.sh r04_vplane_b01_harness vplane_b01_harness
 tools/collect_profiles.sh r04_plane_100m plane_100m
 unset PCR_BENCH_NO_PMC
 timeout 400 python tools/soak.py 150 > $o/r04_soak.txt 2>&1; tail -3 $o/r04_soak.txt
+tools/collect_set_target_profiles.sh > $o/r04_set_target.log 2>&1; tail -4 $o/r04_set_target.log
 cd /tmp; rm -rf $OLDPWD/$o/prof_rare
 timeout 900 rocprofv3 --kernel-trace --output-format rocpd -d $OLDPWD/$o/prof_rare -o r -- python $OLDPWD/tools/rare_event_soak.py 1000000 > $OLDPWD/$o/r04_rare_event.txt 2>&1
 cd $OLDPWD
