@@ -175,8 +175,16 @@ __device__ __forceinline__ void nn_scan_range(const PT *__restrict__ pts, uint32
     for (uint32_t j = s; j < e; j += B) {
         const PT *__restrict__ b = pts + j;
         PT p[B];
+#ifdef PCR_NN_ABLATE_LOADS
+        // developer TIMING experiment (wrong results): ONE record of the batch is fetched, the others are made up from it, the
+        // arithmetic stays -- what the search would cost if a batch were one load instruction instead of four
+        p[0] = b[0];
+#pragma unroll
+        for (int u = 1; u < B; ++u) { p[u] = p[0]; p[u].x += (Real)(1.0e-3 * u); }
+#else
 #pragma unroll
         for (int u = 0; u < B; ++u) p[u] = b[u];
+#endif
 #pragma unroll
         for (int u = 0; u < B; ++u) nn_test<Real, PT, TRACK>(p[u], j + u, qx, qy, qz, best, bj, borig, tk);
     }
