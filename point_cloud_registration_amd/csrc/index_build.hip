@@ -562,7 +562,7 @@ pcr_status pcr_count_nonfinite(pcr_context *ctx, const void *d_xyz, int is_f64, 
     return s;
 }
 
-pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n, float cell_hint, pcr_target *t, bool use_env) {
+pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n, float cell_hint, pcr_target *t, bool use_env, double halo_default) {
     double h = cell_hint > 0 ? (double)cell_hint : 0.5;
     const char *env = use_env ? getenv("PCR_GRID_CELL") : nullptr;
     bool auto_h = !(cell_hint > 0);
@@ -571,7 +571,7 @@ pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n,
     // point, ring 0 certifies every query whose match is closer than 0.1 h + its distance to the cell wall
     // Measured (MI355X): 1.06 M points, converged poses 70 -> 57 us and 84 -> 60 us, first poses +1 %; at 1e8
     // points (+2.8 GB, nothing cache-resident) +3 %: on by default up to 2^24 points.
-    double halo = n <= ((int64_t)1 << 24) ? 0.1 : 0.0;
+    double halo = n <= ((int64_t)1 << 24) ? halo_default : 0.0;
     const char *he = getenv("PCR_HALO");
     if (he && *he) halo = atof(he);
     PCR_TRY((build_grid<float, float, PtF>(ctx, d_xyz, n, h, auto_h, &t->gf, &t->cell_start, &t->cell_seed, &t->pts, &t->occupied,
@@ -632,7 +632,11 @@ pcr_status pcr_build_centroid_filter(pcr_context *ctx, pcr_target *t) {
     pcr_target *f = new pcr_target();
     f->ctx = ctx; f->n = t->n;
     t->filter = f;                                   // (owned by t from here on: freed with it, also on the error path)
-    PCR_TRY(pcr_build_point_grid(ctx, xyz.p, t->n, (float)g.h, f, false));
+    // The filter index takes DEEPER extended lists than a point target (0.4 cell against 0.1): a query sits 0.2-0.5 voxel from its
+    // centroid, i.e. a good part of a (two-voxel) cell, at EVERY pose, and the lists of a few hundred thousand centroids stay in
+    // the caches whatever their depth.  Search us per 6-pose trajectory, margin 0.1 / 0.25 / 0.4 / 0.5 / 0.6 / 0.8 / 1.0 cell:
+    // vplane_10m 3699 / 3643 / 3382 / 3473 / 3397 / 3683 / 3466, ndt_10m 2559 / 2434 / 2252 / 2244 / 2207 / 2590 / 2649.
+    PCR_TRY(pcr_build_point_grid(ctx, xyz.p, t->n, (float)g.h, f, false, 0.4));
     t->filter_band = band;
     return PCR_OK;
 }

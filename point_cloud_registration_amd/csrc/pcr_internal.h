@@ -331,7 +331,8 @@ void pcr_scan_free(pcr_scan *s, void *p);      // one block back to the cache (n
 void pcr_target_release(pcr_target *t);      // frees a target and everything it owns (blocks back to its context's cache)
 
 // ---- index_build.hip
-pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n, float cell_hint, pcr_target *t, bool use_env = true);
+pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n, float cell_hint, pcr_target *t, bool use_env = true,
+                                double halo_default = 0.1);     // halo_default: margin of the extended lists, x cell (PCR_HALO overrides)
 pcr_status pcr_build_centroid_filter(pcr_context *ctx, pcr_target *t);
 pcr_status pcr_build_deep_lists(pcr_context *ctx, pcr_target *t);
 pcr_status pcr_build_centroid_grid(pcr_context *ctx, const double *d_mean, int64_t n, double cell, pcr_target *t);
