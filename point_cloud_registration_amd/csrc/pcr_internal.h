@@ -63,9 +63,13 @@ struct Geom {
     const unsigned long long *rowocc;
     int nyw, nxb;
 };
+#ifndef PCR_HALO2_FRAC
 #define PCR_HALO2_FRAC 0.25      // margin of the deeper list set, x cell
+#endif
 #define PCR_HALO2_AFTER 12       // passes a point target serves before the deeper set is built (~0.3 ms: repaid after ~60 passes)
+#ifndef PCR_HALO2_MOVE
 #define PCR_HALO2_MOVE 0.12      // the deeper set serves passes whose scan moved by at least this x cell since the previous pass
+#endif
 #define PCR_GAP_SHIFT 28
 #define PCR_GAP_MAX 15
 
