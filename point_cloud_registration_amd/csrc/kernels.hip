@@ -550,6 +550,9 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
     const bool one_kernel = pcr_pass_is_fused(ctx, s);
     if (!one_kernel && !s->nn_j) {
         HIP_TRY(pcr_scan_alloc(s, (void **)&s->nn_j, sizeof(uint32_t) * (size_t)(s->n > 0 ? s->n : 1)));
+#ifdef PCR_EXP_SEED
+        HIP_TRY(hipMemsetAsync(s->nn_j, 0xff, sizeof(uint32_t) * (size_t)(s->n > 0 ? s->n : 1), ctx->stream));
+#endif
         s->nn_serial = 0;
     }
     const int nblocks_split = [&] {

@@ -533,7 +533,16 @@ __device__ __forceinline__ void nn_point(const LinArgs &a, const Geom<float> &gf
             nn_search<float, PtF, false, false, HALO != 0, true>(gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo, nullptr, &tk);
             lb2q = fminf(tk.second, tk.pmin);
         } else {
+#ifdef PCR_EXP_SEED
+            // developer TIMING experiment (exact results): what the per-lane search costs when it starts from a near-exact
+            // upper bound -- the match the previous pass left in nn_j (tools/pose0_passes.py repeats ONE pose, so that is the
+            // true neighbour): the potential of any scheme that proposes a near neighbour before the exact search
+            const uint32_t pj = a.nn_j[i];
+            if (pj != PCR_NONE) nn_test<float, PtF, 0>(a.pts[pj], pj, tx, ty, tz, best, bj, bo);
+            nn_search<float, PtF, false, true, HALO != 0, false>(gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
+#else
             nn_search<float, PtF, false, false, HALO != 0, false>(gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
+#endif
             lb2q = best;
         }
         if (TRACK) {

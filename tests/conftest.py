@@ -77,6 +77,21 @@ def g8():
     return g
 
 
+@pytest.fixture(scope="session")
+def g10():
+    """BASELINE configs[2] / [3] at config size (reference run on the 10 M-point cloud and its FULL 10 M-point perturbed
+    scan -- bench.py's vplane_10m / ndt_10m workloads) + the clouds, regenerated and checksum-guarded."""
+    import zlib
+    from point_cloud_registration_amd.synthetic import street_tiled, perturbed_scan
+    g = load_golden("g10_10m_voxel.npz")
+    target = street_tiled(int(g["n"]), seed=0)
+    scan = perturbed_scan(target, None, seed=2)[0]
+    assert zlib.crc32(target.tobytes()) == int(g["crc32_target"]), "street_tiled() no longer reproduces the fixture's cloud"
+    assert zlib.crc32(scan.tobytes()) == int(g["crc32_scan"]), "perturbed_scan() no longer reproduces the fixture's scan"
+    g["target"], g["scan"] = target, scan
+    return g
+
+
 def rel_H(H, Href):
     """Parity metric of SURVEY.md section 8a Q5: max|dH| / max|H_ref|."""
     return float(np.max(np.abs(np.asarray(H) - np.asarray(Href))) / np.max(np.abs(Href)))

@@ -358,3 +358,25 @@ def test_g8_hip_matches_reference_at_b01_size(capi, g8, g8_targets, scan_name):
         dt, dr = _pose_err(T, g8[f"{tag}_final"])
         assert dt <= 1e-4 and dr <= 1e-4, (tag, dt, dr)
     print(f"g8 {scan_name}: worst max|dH|/max|H| vs the reference", {k: f"{v:.1e}" for k, v in worst.items()})
+
+
+# ----------------------------------------------------------------------------- g10: the reference itself at 10 M points
+@pytest.mark.parametrize("cname,vs", [("vplane", 0.5), ("ndt", 1.0)])
+def test_g10_hip_matches_reference_at_10m(capi, g10, cname, vs):
+    """VERDICT r4 missing #4: HIP against what the REFERENCE produced on BASELINE configs[2] / [3] at config size (10 M-point
+    target through the GPU voxel build, the full 10 M-point scan of bench.py's vplane_10m / ndt_10m): H within 1e-5
+    relative, g and e2 within 1e-4, at the identity, a mid pose and T_true; same number of kept voxels."""
+    kind = {"vplane": capi.VPLANE, "ndt": capi.NDT}[cname]
+    ctx = capi.get_context(0)
+    tgt = capi.Target.voxels(ctx, g10["target"], vs, 10)
+    assert tgt.size() == int(g10[f"{cname}_n_voxels"])
+    sc = capi.Scan(ctx, g10["scan"])
+    worst = 0.0
+    for k, T in enumerate(g10["poses"]):
+        H, g, e2, cnt = capi.unpack29(capi.linearize(tgt, sc, kind, T, float(g10["max_dist"])))
+        r = rel_H(H, g10[f"{cname}_H"][k])
+        worst = max(worst, r)
+        assert r <= 1e-5, (cname, k, r)
+        assert np.max(np.abs(g - g10[f"{cname}_g"][k])) <= 1e-4 * np.max(np.abs(g10[f"{cname}_g"][0])), (cname, k)
+        assert abs(e2 - g10[f"{cname}_e2"][k]) <= 1e-4 * abs(g10[f"{cname}_e2"][k]), (cname, k)
+    print(f"g10 {cname}: worst max|dH|/max|H| vs the reference at 10 M points {worst:.1e}")
