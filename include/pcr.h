@@ -115,6 +115,13 @@ PCR_API pcr_status pcr_target_points_create_device(pcr_context *ctx, const float
                                                    pcr_target **out);
 /* caller-supplied normals, PlaneICP.set_target(target, kdree, norm) (plane_icp.py:25-27)  */
 PCR_API pcr_status pcr_target_set_normals(pcr_target *t, const float *normals);
+/* Quirk Q6 -- PlaneICP.set_target builds its KD-tree on the ORIGINAL array (plane_icp.py:22) and gathers from the float32
+ * copy (plane_icp.py:20,44): a float64 target is SEARCHED in float64 (queries up-cast, float64 distances, float64 gate,
+ * plane_icp.py:40-41); so is KDTree(float64 data).query (kdtree.py:18-21).  xyz64 = the (N,3) float64 array whose
+ * float32 rounding the target was created from; PCR_PLANE passes and pcr_nn_query_f64 then return the float64 search's
+ * neighbour (float32 filter search over the index + float64 check, float64 box search for what that cannot separate);
+ * PCR_ICP keeps the float32 search (icp.py:19-20 builds its tree on the float32 copy).  +32 bytes per point.          */
+PCR_API pcr_status pcr_target_points_set_f64(pcr_target *t, const double *xyz64);
 /* k-NN PCA normals, estimate_norm_with_tree (estimate_normals.py:27-87).  compat != 0 keeps
  * the reference's float32 single-pass covariance; normals_out (N,3) may be NULL.           */
 PCR_API pcr_status pcr_target_estimate_normals(pcr_target *t, int k, int compat, float *normals_out);

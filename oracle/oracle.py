@@ -22,6 +22,7 @@ _LIB = None
 
 ICP, PLANE, VPLANE, NDT = 0, 1, 2, 3
 FLAG_ICP_RR_QUIRK = 1
+FLAG_GATE_F64 = 2       # quirk Q6: float64 gate on the float64 tree's distances (plane_icp.py:22,41)
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -229,14 +230,19 @@ def plus(T, dx):
 class TargetPoints:
     """ICP / PlaneICP target: float32 copy of the cloud (+ normals) and an exact NN index."""
 
-    def __init__(self, target, normals=None, k=15, cell=None, compat_normals=True):
+    def __init__(self, target, normals=None, k=15, cell=None, compat_normals=True, tree_f64=False):
+        """tree_f64 (quirk Q6, plane_icp.py:20-22): PlaneICP builds its KD-tree on the ORIGINAL array, so a float64
+        target is SEARCHED in float64 (queries up-cast, float64 distances, float64 gate) while the matched records are
+        gathered from the float32 copy (plane_icp.py:20,44).  Only meaningful when `target` is float64."""
         self.pts = _c(target, np.float32)
+        self.tree_f64 = bool(tree_f64) and np.asarray(target).dtype == np.float64
+        self.pts64 = _c(target, np.float64) if self.tree_f64 else None
         self._brute = self.pts.shape[0] <= 4096
         if not self._brute:
             if cell is None:
                 ext = self.pts.max(0) - self.pts.min(0)
                 cell = max(float(np.cbrt(np.prod(np.maximum(ext, 1e-3)) / max(self.pts.shape[0], 1)) * 2.0), 1e-3)
-            self.grid = Grid(self.pts, cell)
+            self.grid = Grid(self.pts64 if self.tree_f64 else self.pts, cell)
         self.normals = None
         if normals is not None:
             self.normals = _c(normals, np.float32)
@@ -248,6 +254,8 @@ class TargetPoints:
 
     def query(self, q, r_max=np.inf):
         if self._brute:
+            if self.tree_f64:
+                return nn_brute_f64(self.pts64, q)
             d, i = nn_brute(self.pts, q)
             return d.astype(np.float64), i
         return self.grid.query(q, r_max)
@@ -280,6 +288,8 @@ def calc_H_g_e2(kind, target, cur_T, source, max_dist=2.0, flags=FLAG_ICP_RR_QUI
     if kind == ICP:
         H, g, e2, cnt = linearize(kind, cur_T, source, st, target.pts, None, dist, idx, max_dist, flags)
     elif kind == PLANE:
+        if getattr(target, "tree_f64", False):
+            flags |= FLAG_GATE_F64
         H, g, e2, cnt = linearize(kind, cur_T, source, st, target.pts, target.normals, dist, idx, max_dist, flags)
     elif kind == VPLANE:
         H, g, e2, cnt = linearize(kind, cur_T, source, st, target.mean, target.norm, dist, idx, max_dist, flags)

@@ -38,7 +38,9 @@
 #define ORC_API __attribute__((visibility("default")))
 
 enum { ORC_ICP = 0, ORC_PLANE = 1, ORC_VPLANE = 2, ORC_NDT = 3 };
-enum { ORC_FLAG_ICP_RR_QUIRK = 1 };   /* quirk Q1: g1 = sum p x (R r)  (icp.py:53-54) */
+enum { ORC_FLAG_ICP_RR_QUIRK = 1,      /* quirk Q1: g1 = sum p x (R r)  (icp.py:53-54) */
+       ORC_FLAG_GATE_F64 = 2 };        /* quirk Q6: a float64 target's tree returns float64 distances, so plane_icp.py:41
+                                          gates in float64 (records stay the float32 copy, plane_icp.py:20,44) */
 
 ORC_API int orc_max_threads(void) {
 #ifdef _OPENMP
@@ -333,7 +335,7 @@ static void lin_icp(const double T[16], const float *src, const float *st, int64
  * voxelized_plane_icp.py:23-64 (voxel mean + voxel normal, float64 records).           */
 static void lin_plane(const double T[16], const float *src, const float *st, int64_t n,
                       const void *q_rec, const void *n_rec, int rec_f64,
-                      const double *dist, const int64_t *idx, double max_dist, double out[29]) {
+                      const double *dist, const int64_t *idx, double max_dist, int gate_f64, double out[29]) {
     const double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
     memset(out, 0, 29 * sizeof(double));
 #pragma omp parallel
@@ -342,7 +344,7 @@ static void lin_plane(const double T[16], const float *src, const float *st, int
 #pragma omp for schedule(static)
         for (int64_t i = 0; i < n; ++i) {
             if (idx[i] < 0) continue;
-            if (rec_f64) { if (!(dist[i] < max_dist)) continue; }
+            if (rec_f64 || gate_f64) { if (!(dist[i] < max_dist)) continue; }
             else { if (!((float)dist[i] < (float)max_dist)) continue; }   /* plane_icp.py:41 */
             double nv[3], diff[3];
             if (rec_f64) {
@@ -424,8 +426,8 @@ ORC_API int orc_linearize(int kind, const double T[16], const float *src, const 
                           double max_dist, unsigned flags, double out[29]) {
     switch (kind) {
     case ORC_ICP: lin_icp(T, src, src_trans, n, (const float *)rec_a, dist, idx, max_dist, flags, out); return 0;
-    case ORC_PLANE: lin_plane(T, src, src_trans, n, rec_a, rec_b, 0, dist, idx, max_dist, out); return 0;
-    case ORC_VPLANE: lin_plane(T, src, src_trans, n, rec_a, rec_b, 1, dist, idx, max_dist, out); return 0;
+    case ORC_PLANE: lin_plane(T, src, src_trans, n, rec_a, rec_b, 0, dist, idx, max_dist, (flags & ORC_FLAG_GATE_F64) != 0, out); return 0;
+    case ORC_VPLANE: lin_plane(T, src, src_trans, n, rec_a, rec_b, 1, dist, idx, max_dist, 1, out); return 0;
     case ORC_NDT: lin_ndt(T, src, src_trans, n, (const double *)rec_a, (const double *)rec_b, dist, idx, max_dist, out); return 0;
     default: return -1;
     }

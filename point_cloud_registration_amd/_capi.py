@@ -54,6 +54,7 @@ PROTOTYPES = {
     "pcr_target_points_create": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_float, C.POINTER(_vp)]),
     "pcr_target_points_create_device": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_float, C.POINTER(_vp)]),
     "pcr_target_set_normals": (C.c_int, [_vp, _f32p]),
+    "pcr_target_points_set_f64": (C.c_int, [_vp, _f64p]),
     "pcr_target_estimate_normals": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "pcr_target_get_normals": (C.c_int, [_vp, _f32p]),
     "pcr_target_voxels_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_double, C.c_int, C.POINTER(_vp)]),
@@ -165,6 +166,8 @@ def lib():
         except AttributeError:
             if not os.environ.get("PCR_LIB"):
                 raise
+            if name == "pcr_abi_version":
+                raise PcrError(f"{LIB_PATH} predates pcr_abi_version (ABI < 4): too old for this binding, rebuild it")
             # an A/B library built from an older revision (tools/build_rev_lib.sh): instrumentation entry points it
             # does not have yet read as "nothing" (status 0, outputs untouched)
             setattr(L, name, lambda *a, **k: 0)
@@ -419,6 +422,15 @@ class Target:
         check(lib().pcr_target_size(self.handle, C.byref(n)))
         return n.value
 
+    def set_points_f64(self, xyz64):
+        """Quirk Q6 (plane_icp.py:20-22, kdtree.py:18-21): the float64 coordinates of the points this target was created
+        from -- PlaneICP passes and ``nn_query`` then search in float64, as the reference's tree over a float64 array does."""
+        xyz64 = np.ascontiguousarray(xyz64, dtype=np.float64)
+        if xyz64.shape != (self.size(), 3):
+            raise ValueError("xyz64 must have the shape of the target")
+        check(lib().pcr_target_points_set_f64(self.handle, xyz64))
+        self.has_f64 = True
+
     def set_normals(self, normals):
         check(lib().pcr_target_set_normals(self.handle, np.ascontiguousarray(normals, dtype=np.float32)))
 
@@ -459,7 +471,7 @@ class Target:
         q = np.ascontiguousarray(q, dtype=np.float32)
         m = q.shape[0]
         idx = np.empty(m, np.int64)
-        if self.is_voxel:
+        if self.is_voxel or getattr(self, "has_f64", False):
             dist = np.empty(m, np.float64)
             check(lib().pcr_nn_query_f64(self.handle, q, m, float(r_max), dist, idx))
         else:

@@ -445,7 +445,7 @@ static void target_free(pcr_target *t) { pcr_target_release(t); }
 void pcr_target_release(pcr_target *t) {
     if (!t) return;
     target_free(t->filter);
-    void *ptrs[] = {t->cell_start, t->cell_seed, t->rowocc, t->cs_h, t->pts_h, t->j_h, t->cs_h2, t->pts_h2, t->j_h2, t->pts, t->pn, t->means, t->vnorm, t->vicov,
+    void *ptrs[] = {t->cell_start, t->cell_seed, t->rowocc, t->cs_h, t->pts_h, t->j_h, t->cs_h2, t->pts_h2, t->j_h2, t->pts, t->pn, t->pts64, t->means, t->vnorm, t->vicov,
                     t->st_mean, t->st_cov, t->st_norm, t->st_icov, t->st_counts, t->st_keys};
     if (t->ctx) (void)hipSetDevice(t->ctx->device);
     for (void *p : ptrs) pcr_persist_free(t->ctx, p);
@@ -503,6 +503,18 @@ extern "C" pcr_status pcr_target_set_normals(pcr_target *t, const float *normals
     PCR_TRY(pcr_permute_normals(ctx, d_nrm.p, t->n, t->pts, t->pn));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PCR_OK;
+}
+
+// quirk Q6 (plane_icp.py:20-22): the float64 coordinates of the points the target was created from
+extern "C" pcr_status pcr_target_points_set_f64(pcr_target *t, const double *xyz64) {
+    PCR_REQUIRE(t && xyz64, "NULL argument");
+    PCR_REQUIRE(!t->is_voxel, "float64 search coordinates belong to point targets");
+    pcr_context *ctx = t->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    CtxScope scope(ctx);
+    DevBuf<double> d_xyz;
+    PCR_TRY(upload<double>(ctx, xyz64, (size_t)t->n * 3, &d_xyz));
+    return pcr_attach_points_f64(ctx, t, d_xyz.p);
 }
 
 __global__ void __launch_bounds__(256) k_unpermute_normals(const PtN *__restrict__ pn, int64_t n, float *out) {

@@ -662,6 +662,73 @@ pcr_status pcr_permute_normals(pcr_context *ctx, const float *d_in, int64_t n, c
     return PCR_OK;
 }
 
+// ---- quirk Q6: the float64 coordinates of a point target, in the index's order --------------------------------
+// out[j] = float64 coordinates of the point stored at cell-sorted position j (w = its original index, as in the centroid
+// arrays); dev = the largest distance between a point's float64 position and the float32 record the index was built on
+// (positive doubles order like their bit patterns: one 64-bit atomicMax)
+__global__ void __launch_bounds__(256) k_perm_pts64(const double *__restrict__ xyz64, int64_t n, const PtF *__restrict__ pts,
+                                                    PtD *out, unsigned long long *dev) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double d = 0.0;
+    if (j < n) {
+        const PtF p = pts[j];
+        const size_t i = __float_as_uint(p.w);
+        const double x = xyz64[3 * i], y = xyz64[3 * i + 1], z = xyz64[3 * i + 2];
+        out[j] = make_double4(x, y, z, __longlong_as_double((long long)i));
+        const double ex = x - (double)p.x, ey = y - (double)p.y, ez = z - (double)p.z;
+        d = __builtin_sqrt((ex * ex + ey * ey) + ez * ez);
+        if (!(d >= 0.0)) d = __longlong_as_double(0x7ff0000000000000LL);      // NaN: refuse (the caller checks for inf)
+    }
+    for (int off = 32; off >= 1; off >>= 1) d = fmax(d, __shfl_xor(d, off, 64));
+    if ((threadIdx.x & 63) == 0 && d > 0.0) atomicMax(dev, (unsigned long long)__double_as_longlong(d));
+}
+
+pcr_status pcr_attach_points_f64(pcr_context *ctx, pcr_target *t, const double *d_xyz64) {
+    const int64_t n = t->n;
+    DevBuf<PtD> out;
+    HIP_TRY(out.alloc_exact((size_t)(n > 0 ? n : 1) + PCR_PTS_PAD));
+    {   // sentinel records behind the last point (nn_scan_range over-reads a batch): +inf coordinates, index ~0
+        PtD pad[PCR_PTS_PAD];
+        for (int i = 0; i < PCR_PTS_PAD; ++i) {
+            pad[i].x = pad[i].y = pad[i].z = INFINITY;
+            const long long m = 0xffffffffLL; memcpy(&pad[i].w, &m, 8);
+        }
+        HIP_TRY(hipMemcpyAsync(out.p + (size_t)n, pad, sizeof pad, hipMemcpyHostToDevice, ctx->stream));
+    }
+    DevBuf<unsigned long long> dev;
+    HIP_TRY(dev.alloc(1));
+    HIP_TRY(hipMemsetAsync(dev.p, 0, sizeof(unsigned long long), ctx->stream));
+    if (n > 0) {
+        hipLaunchKernelGGL(k_perm_pts64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_xyz64, n,
+                           (const PtF *)t->pts, out.p, dev.p);
+        HIP_TRY(hipGetLastError());
+    }
+    unsigned long long bits = 0;
+    HIP_TRY(hipMemcpyAsync(&bits, dev.p, sizeof bits, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    double band;
+    memcpy(&band, &bits, 8);
+    const Geom<float> &gf = t->gf;
+    if (!(band <= 0.25 * (double)gf.h)) {
+        pcr_set_error("the float64 coordinates are not those of the target's float32 points (a point moves by %g m, cell %g m)",
+                      band, (double)gf.h);
+        return PCR_ERR_INVALID;
+    }
+    pcr_persist_free(ctx, t->pts64);
+    t->pts64 = out.release();
+    t->band64 = band * 1.01 + 1e-30;
+    Geom<double> &g = t->gq;
+    g.ox = (double)gf.ox; g.oy = (double)gf.oy; g.oz = (double)gf.oz;
+    g.h = (double)gf.h; g.inv_h = (double)gf.inv_h;
+    g.nx = gf.nx; g.ny = gf.ny; g.nz = gf.nz;
+    // the cells were assigned to the float32 records in float32 arithmetic (gf.slack covers that); a point's float64
+    // position lies within band64 of its record
+    g.slack = (double)gf.slack * 2.0 + t->band64;
+    g.cs_mask = gf.cs_mask;
+    g.seed = nullptr; g.halo = 0; g.cs_h = nullptr; g.pts_h = nullptr; g.j_h = nullptr; g.rowocc = nullptr; g.nyw = 0; g.nxb = 0;
+    return PCR_OK;
+}
+
 struct ColSel { int c[9]; int n; };
 __global__ void __launch_bounds__(256) k_perm_f64(const double *__restrict__ in, int64_t n, int stride, ColSel sel,
                                                   const PtD *__restrict__ means, double *out) {

@@ -196,13 +196,14 @@ __global__ void __launch_bounds__(256, VOXEL == 2 ? PCR_VOX_WAVES : 5) k_nn_scan
 // +8 VALU operations per candidate -- was measured on both 10 M configs in round 4: search 570 -> 640 us and 380 -> 429 us per
 // pass, more than the pending points cost anywhere.  The fused small-scan kernel, where one extra search chain doubles the
 // longest wave, does use it.)
-template <int HALO, int LOCAL>
+// Q6 (round 5): the same kernel in front of the float64 coordinates of a float64 POINT target (pass_device.h: nn_filter_core)
+template <int HALO, int LOCAL, int Q6 = 0>
 __global__ void __launch_bounds__(256, 5) k_nn_filter(const LinArgs a) {
     PoseK P;
     if (!load_pose<false>(a, P)) return;
     auto body = [&](int64_t first, int64_t end) {
         const int64_t i = first + (threadIdx.x & 63);
-        if (i < end) nn_point_filter<HALO, 0>(a, P, i);
+        if (i < end) nn_point_filter<HALO, 0, Q6>(a, P, i);
     };
     nn_tile_loop<LOCAL, 64>(a, body);
 }
@@ -219,9 +220,10 @@ __global__ void __launch_bounds__(256) k_nn_fix(const LinArgs a) {
     }
 }
 #endif
-static void launch_nn_filter(bool halo, int local, bool separate_fix, dim3 grid, hipStream_t st, const LinArgs &a) {
+static void launch_nn_filter(bool halo, int local, bool separate_fix, bool q6, dim3 grid, hipStream_t st, const LinArgs &a) {
     const dim3 block(256);
-#define PCR_NF_CASE(H, L) hipLaunchKernelGGL((k_nn_filter<H, L>), grid, block, 0, st, a)
+#define PCR_NF_CASE(H, L) do { if (q6) hipLaunchKernelGGL((k_nn_filter<H, L, 1>), grid, block, 0, st, a); \
+                               else hipLaunchKernelGGL((k_nn_filter<H, L, 0>), grid, block, 0, st, a); } while (0)
     // (local == 2, "decided on the device from the size of the step", is not instantiated here: both tile loops in one
     // kernel around the tracking search spill 736 bytes per lane; the device-resident loop keeps the global counters)
     if (halo) { if (local == 1) PCR_NF_CASE(1, 1); else PCR_NF_CASE(1, 0); }
@@ -398,7 +400,7 @@ __global__ void __launch_bounds__(256, FIX ? 4 : 1) k_reduce_finalize(const LinA
     PoseK P;
     if (!load_pose<true>(a, P)) return;
     const TileIter it(a);
-    if (FIX && (KIND == PCR_VPLANE || KIND == PCR_NDT)) {
+    if (FIX && KIND != PCR_ICP) {              // (PLANE: the float64 search of a float64 point target, quirk Q6)
         if ((uint32_t)__builtin_amdgcn_readfirstlane((int)*(volatile const uint32_t *)a.pending) == a.stamp)
             fix_pending(a, P, it);
     }
@@ -453,6 +455,25 @@ __global__ void __launch_bounds__(256) k_nn_query(Geom<Real> g, const PT *pts, c
     if (bj != PCR_NONE && rmax < RealTraits<Real>::inf() && !(d < rmax)) bj = PCR_NONE;
     dist[i] = bj == PCR_NONE ? RealTraits<Real>::inf() : d;
     idx[i] = bj == PCR_NONE ? (int64_t)-1 : (int64_t)bo;
+}
+
+// KDTree(float64 data).query (kdtree.py:18-21; quirk Q6): the float32 search over the index nominates, the float64 box search
+// through the nominee (nn_box_f64: every point whose float64 position can lie inside that ball) decides by (float64
+// distance, original index).  The fine seam: no certification shortcut, every query runs both.
+template <bool HALO>
+__global__ void __launch_bounds__(256) k_nn_query_q6(Geom<float> gf, const PtF *pts, const uint32_t *cs, Geom<double> gq, const PtD *pts64,
+                                                     const float *q, int64_t m, float bound2_f, double rmax, double *dist, int64_t *idx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const float qx = q[3 * i], qy = q[3 * i + 1], qz = q[3 * i + 2];
+    float best; uint32_t bj, bo;
+    nn_search<float, PtF, false, false, HALO>(gf, pts, cs, qx, qy, qz, bound2_f, best, bj, bo);
+    double bd = __longlong_as_double(0x7ff0000000000000LL);
+    if (bo != PCR_NONE) nn_box_f64(gq, pts64, cs, (double)qx, (double)qy, (double)qz, bj, bd, bj, bo);
+    const double d = __builtin_sqrt(bd);
+    if (bo != PCR_NONE && !(d < rmax)) bo = PCR_NONE;
+    dist[i] = bo == PCR_NONE ? __longlong_as_double(0x7ff0000000000000LL) : d;
+    idx[i] = bo == PCR_NONE ? (int64_t)-1 : (int64_t)bo;
 }
 
 // =============================================================================================
@@ -519,6 +540,7 @@ struct Pass {
     double motion;       // typical displacement of the scan since the previous pass over it (host-driven passes; -1 unknown)
     int nn_mode;         // PCR_NN_FULL / TRACK / LIST
     bool reuse_ready;    // the scan has the buffers of the certified-reuse path
+    bool q6;             // PlaneICP pass over a float64 point target: float64 search (quirk Q6, pcr_target::pts64)
 };
 
 bool pcr_pass_is_fused(const pcr_context *ctx, const pcr_scan *s) {
@@ -547,7 +569,9 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
     PCR_TRY(pcr_ensure_scratch(ctx, s->n));
     // one fused kernel or search + reduce?  variant 2 (default) decides by size: a small scan is latency-bound
     // and runs fused (tools/variant_crossover.py: 100 k points 74 vs 80 us per pass, 300 k 97 vs 92, 1.06 M 190 vs 151)
-    const bool one_kernel = pcr_pass_is_fused(ctx, s);
+    // quirk Q6: a PlaneICP pass over a float64 point target searches in float64 -- always search + reduce, always a full search
+    const bool q6 = kind == PCR_PLANE && !t->is_voxel && t->pts64 != nullptr;
+    const bool one_kernel = pcr_pass_is_fused(ctx, s) && !q6;
     if (!one_kernel && !s->nn_j) {
         HIP_TRY(pcr_scan_alloc(s, (void **)&s->nn_j, sizeof(uint32_t) * (size_t)(s->n > 0 ? s->n : 1)));
 #ifdef PCR_EXP_SEED
@@ -562,7 +586,7 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
         return nb < 8 ? 8 : nb;
     }();
     ps->reuse_ready = false;
-    if (!one_kernel && ctx->reuse != 0 && (ctx->nn_mode == 0 || ctx->nn_mode == 3) && s->n > 0) {
+    if (!one_kernel && !q6 && ctx->reuse != 0 && (ctx->nn_mode == 0 || ctx->nn_mode == 3) && s->n > 0) {
         if (!s->lb2) {
             const size_t words = (((size_t)s->n + 63) / 64 + 31) & ~(size_t)15;     // whole 16-word chunks + slack
             HIP_TRY(pcr_scan_alloc(s, (void **)&s->lb2, sizeof(float) * (size_t)s->n));
@@ -578,7 +602,7 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
         }
         ps->reuse_ready = true;
     }
-    ps->ctx = ctx; ps->t = t; ps->s = s; ps->kind = kind; ps->one_kernel = one_kernel;
+    ps->ctx = ctx; ps->t = t; ps->s = s; ps->kind = kind; ps->one_kernel = one_kernel; ps->q6 = q6;
     LinArgs &a = ps->a;
     memset(&a, 0, sizeof a);
     a.sx = s->x; a.sy = s->y; a.sz = s->z; a.n = s->n;
@@ -606,9 +630,16 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
         a.gf = t->filter->gf; a.pts = t->filter->pts; a.cs_f = t->filter->cell_start;
         a.band_f = (float)(t->filter_band * 1.000001);
     }
+    if (q6) {
+        // the filter is the target's own float32 index (a.gf / a.pts / cell_start as they are); the float64 side reads the
+        // float64 coordinates in the same order through the voxel-target fields of the kernels
+        a.gd = t->gq; a.means = t->pts64; a.cs_f = t->cell_start;
+        a.band_f = (float)(t->band64 * 1.000001);
+        flags |= PCR_IFLAG_NOGATE;
+    }
     // the deeper set of extended lists of a point target: built once the target has served PCR_HALO2_AFTER search + reduce
     // passes (a failed build is not an error: the pass runs on the first set)
-    if (!t->is_voxel && !one_kernel && t->cs_h && ctx->nn_mode == 0) {
+    if (!t->is_voxel && !one_kernel && !q6 && t->cs_h && ctx->nn_mode == 0) {
         if (!t->deep_tried && ++t->split_passes > PCR_HALO2_AFTER) {
             t->deep_tried = true;
             if (pcr_build_deep_lists(ctx, t) != PCR_OK) (void)hipGetLastError();
@@ -699,7 +730,7 @@ static int host_choose_mode(const Pass *ps, const double T[16], double *motion_o
 
 template <int KIND>
 static void launch_reduce_kind(const Pass *ps, bool fused, bool fix, dim3 grid) {
-    if constexpr (KIND == PCR_VPLANE || KIND == PCR_NDT) {
+    if constexpr (KIND != PCR_ICP) {
         if (fused && fix) {
             hipLaunchKernelGGL((k_reduce_finalize<KIND, 1>), grid, dim3(256), 0, ps->ctx->stream, ps->a, ps->f);
             return;
@@ -756,7 +787,7 @@ static pcr_status pass_enqueue(Pass *ps) {
     } else {
         const bool vox = ps->t->is_voxel != 0;
         const int mode = ps->nn_mode;
-        const bool filter = vox && mode == PCR_NN_FULL && a.band_f > 0.f;
+        const bool filter = (vox && mode == PCR_NN_FULL && a.band_f > 0.f) || ps->q6;
         if (mode == PCR_NN_LIST) {
             // the previous matches that are provably still exact need no search (k_certify)
             pcr_prof_begin(ctx, PCR_K_CERTIFY, &ev);
@@ -768,7 +799,7 @@ static pcr_status pass_enqueue(Pass *ps) {
         pcr_prof_begin(ctx, PCR_K_NN, &ev);
         {   // exactly one resident generation of waves; they share the tiles dynamically
             RoctxRange range("pcr:nn_search");
-            int64_t nb = (int64_t)ctx->num_cu * ctx->nn_blocks_per_cu[filter ? 3 : vox ? 1 : (ctx->nn_mode == 2 ? 2 : 0)];
+            int64_t nb = (int64_t)ctx->num_cu * ctx->nn_blocks_per_cu[filter ? 3 : vox ? 1 : (ctx->nn_mode == 2 && !ps->q6 ? 2 : 0)];
             // tiles of the hand-out: 64 points per wave, or the 1024-point chunks of a LIST pass (one block per chunk)
             const int64_t tiles = mode == PCR_NN_LIST ? (a.n + PCR_LIST_CHUNK - 1) / PCR_LIST_CHUNK : (a.n + 63) / 64;
             const int64_t need = mode == PCR_NN_LIST ? tiles : (tiles + 3) / 4;
@@ -790,11 +821,11 @@ static pcr_status pass_enqueue(Pass *ps) {
             if (ctx->tile_local >= 0) local = ctx->tile_local;
             ps->a.sched_local = local;
 #ifdef PCR_DEV
-            if (!vox && ctx->nn_mode == 2) {
+            if (!vox && !ps->q6 && ctx->nn_mode == 2) {
                 pcr_dev_launch_coop(nn_grid, ctx->stream, a);
             } else
 #endif
-            if (!vox) {
+            if (!vox && !ps->q6) {
                 // host-driven pass: the list set by how far the scan moved since the previous pass (unknown: the deeper one)
                 if (a.pose == nullptr && a.halo2_f > 0.f && mode == PCR_NN_FULL && !(ps->motion >= 0.0 && ps->motion < ps->f.deep_len)) {
                     ps->a.gf.halo = a.halo2_f; ps->a.gf.cs_h = a.cs_h2; ps->a.gf.pts_h = a.pts_h2; ps->a.gf.j_h = a.j_h2;
@@ -806,7 +837,8 @@ static pcr_status pass_enqueue(Pass *ps) {
                     ctx->filter_stamp = 1;
                 }
                 ps->a.stamp = ctx->filter_stamp;
-                launch_nn_filter(ps->t->filter->cs_h != nullptr, ps->a.sched_local, !ps->fused_fin, nn_grid, ctx->stream, a);
+                const bool fhalo = ps->q6 ? ps->t->cs_h != nullptr : ps->t->filter->cs_h != nullptr;
+                launch_nn_filter(fhalo, ps->a.sched_local == 1 ? 1 : 0, !ps->fused_fin, ps->q6, nn_grid, ctx->stream, a);
             } else if (ps->t->gd.rowocc != nullptr && (ctx->vox_occ >= 0 ? ctx->vox_occ != 0 : a.md_d / ps->t->gd.h + 2.0 >= 5.0)) {
                 launch_nn_scan<2>(mode, false, ps->a.sched_local, nn_grid, ctx->stream, a);
             } else {
@@ -819,7 +851,7 @@ static pcr_status pass_enqueue(Pass *ps) {
         RoctxRange range("pcr:reduce");
         switch (ps->kind) {
         case PCR_ICP: launch_reduce_kind<PCR_ICP>(ps, ps->fused_fin, false, grid); break;
-        case PCR_PLANE: launch_reduce_kind<PCR_PLANE>(ps, ps->fused_fin, false, grid); break;
+        case PCR_PLANE: launch_reduce_kind<PCR_PLANE>(ps, ps->fused_fin, ps->q6, grid); break;
         case PCR_VPLANE: launch_reduce_kind<PCR_VPLANE>(ps, ps->fused_fin, filter, grid); break;
         default: launch_reduce_kind<PCR_NDT>(ps, ps->fused_fin, filter, grid); break;
         }
@@ -1069,8 +1101,19 @@ pcr_status pcr_run_nn(pcr_target *t, const float *d_q, int64_t m, double r_max, 
         else
             hipLaunchKernelGGL((k_nn_query<float, PtF, false>), grid, block, 0, ctx->stream, t->gf, t->pts, t->cell_start, d_q, m,
                                bound2, bounded ? (float)r_max : inf, (float *)d_dist, d_idx);
+    } else if (!t->is_voxel) {
+        PCR_REQUIRE(t->pts64 != nullptr, "pcr_nn_query_f64 needs a voxel target or a point target with float64 coordinates (pcr_target_points_set_f64)");
+        // the float32 search must reach every point whose FLOAT64 position lies within r_max: r_max + band, a little more
+        const double b = (r_max + t->band64) * 1.00002;
+        const float bound2 = bounded ? (float)(b * b * 1.000001) : __builtin_inff();
+        const double rmax = bounded ? r_max : __builtin_inf();
+        if (t->cs_h)
+            hipLaunchKernelGGL((k_nn_query_q6<true>), grid, block, 0, ctx->stream, t->gf, t->pts, t->cell_start, t->gq, t->pts64, d_q, m,
+                               bound2, rmax, (double *)d_dist, d_idx);
+        else
+            hipLaunchKernelGGL((k_nn_query_q6<false>), grid, block, 0, ctx->stream, t->gf, t->pts, t->cell_start, t->gq, t->pts64, d_q, m,
+                               bound2, rmax, (double *)d_dist, d_idx);
     } else {
-        PCR_REQUIRE(t->is_voxel, "pcr_nn_query_f64 needs a voxel target");
         const double inf = __builtin_inf();
         const double b = r_max * (1.0 + 1e-6);
         hipLaunchKernelGGL((k_nn_query<double, PtD, false>), grid, block, 0, ctx->stream, t->gd, t->means, t->cell_start, d_q, m,

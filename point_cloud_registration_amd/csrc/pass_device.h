@@ -211,8 +211,11 @@ __device__ __forceinline__ void acc_ndt(double *acc, const PoseK &a, double x, d
 // the gate of the reference (icp.py:34, plane_icp.py:41, voxelized_plane_icp.py:38, ndt.py:33: dist < max_dist, strict), on
 // the distance exactly as the search computes it (nn_test): the reduce kernels apply it themselves, so that the
 // search may leave UNGATED matches behind for the next pass (certified reuse)
+// (PCR_IFLAG_NOGATE, quirk Q6: the float64 search of a float64 point target already applied the reference's float64 gate
+// -- its tree returns float64 distances, plane_icp.py:22,40-41 -- so the float32 records' own distance must not gate again)
+#define PCR_IFLAG_NOGATE (1u << 27)
 __device__ __forceinline__ bool gate_f32(const LinArgs &a, float dx, float dy, float dz) {
-    return __builtin_sqrtf(dist2_f32(dx, dy, dz)) < a.md_f;
+    return (a.flags & PCR_IFLAG_NOGATE) != 0 || __builtin_sqrtf(dist2_f32(dx, dy, dz)) < a.md_f;
 }
 __device__ __forceinline__ bool gate_f64(const LinArgs &a, double dx, double dy, double dz) {
     return __builtin_sqrt((dx * dx + dy * dy) + dz * dz) < a.md_d;
@@ -374,7 +377,7 @@ struct TileIter {
 // for small ones, where a pass is a chain of dependent cold misses rather than a throughput problem: one
 // launch less, no round trip of the matches through HBM (100 k-point scan: 48.8 vs 58.9 us per pass).
 // The host picks per launch (pcr_set_variant: 2 = automatic, the default).
-template <int HALO, int SETTLE, int B>
+template <int HALO, int SETTLE, int B, int Q6 = 0>
 __device__ __forceinline__ bool nn_filter_core(const LinArgs &a, float tx, float ty, float tz, uint32_t &w, double &d);
 
 // FILT (voxel kinds, round 4): the centroid search runs the float32 filter search with two-way settling (nn_filter_core)
@@ -595,8 +598,13 @@ __device__ __forceinline__ bool nn_is_pending(uint32_t j) { return (j & PCR_PEND
 // third candidate inside the margin is left pending.
 // (the search + check for one transformed point: returns true when the answer is CERTIFIED -- w = cell-sorted index of the
 // nearest centroid or PCR_NONE when nothing lies within the search bound, d = its squared float64 distance)
-template <int HALO, int SETTLE, int B>
+// Q6 (round 5; quirk Q6, plane_icp.py:20-22: a float64 PlaneICP target is SEARCHED in float64): the same filter with the
+// target's OWN float32 index in front and the float64 coordinates of the same points, kept in the index's cell-sorted order
+// (a.means = pcr_target::pts64), behind it -- the winner is addressed by its cell-sorted index fj, which is also what the
+// reduce kernel gathers the float32 record with; its original index (the tie rule) sits in pts64[fj].w.
+template <int HALO, int SETTLE, int B, int Q6>
 __device__ __forceinline__ bool nn_filter_core(const LinArgs &a, float tx, float ty, float tz, uint32_t &w, double &d) {
+    static_assert(!(Q6 && SETTLE), "two-way settling tracks original indices only");
     uint32_t fj = PCR_NONE, fo = PCR_NONE;
     float best = a.bound2_ff;
     NNTrack<float> tk;
@@ -604,6 +612,7 @@ __device__ __forceinline__ bool nn_filter_core(const LinArgs &a, float tx, float
     nn_search<float, PtF, false, false, HALO != 0, SETTLE ? 2 : 1, false, B>(a.gf, a.pts, a.cs_f, tx, ty, tz, a.bound2_ff, best, fj, fo, nullptr, &tk);
     w = PCR_NONE; d = 0.0;         // nothing within bound + band among the rounded centroids: nothing within the gate
     if (fo == PCR_NONE) return true;
+    if (Q6) fo = fj;
     const PtD m = a.means[fo];
     const double dx = (double)tx - m.x, dy = (double)ty - m.y, dz = (double)tz - m.z;
     d = (dx * dx + dy * dy) + dz * dz;
@@ -623,13 +632,13 @@ __device__ __forceinline__ bool nn_filter_core(const LinArgs &a, float tx, float
     return cert;
 }
 
-template <int HALO, int SETTLE>
+template <int HALO, int SETTLE, int Q6 = 0>
 __device__ __forceinline__ void nn_point_filter(const LinArgs &a, const PoseK &P, int64_t i) {
     const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
     float tx, ty, tz;
     xform(P, x, y, z, tx, ty, tz);
     uint32_t w; double d;
-    const bool cert = nn_filter_core<HALO, SETTLE, PCR_NN_BATCH>(a, tx, ty, tz, w, d);
+    const bool cert = nn_filter_core<HALO, SETTLE, PCR_NN_BATCH, Q6>(a, tx, ty, tz, w, d);
     uint32_t out = (w != PCR_NONE && __builtin_sqrt(d) < a.md_d) ? w : PCR_NONE;
 #ifdef PCR_DEV
     if (!cert && !(a.flags & (2u << 28))) {          // (PCR_FIX_DEBUG=2, timing only: the nominee is taken unchecked)
@@ -650,14 +659,11 @@ __device__ __forceinline__ void nn_point_filter(const LinArgs &a, const PoseK &P
 // by slab, the entries of five rows requested together and the rows scanned with the nominee as the running best.
 // Measured inside k_reduce_finalize<.., FIX> (developer build, PCR_FIX_DEBUG: stream only / + walk of nn_j / + searches):
 // vplane_10m 72 / 83 / 125 us with the ring search for boxes wider than 3 x 3 rows, ndt_10m 100 / 111 / 118 us.
-__device__ __forceinline__ void nn_point_fix(const LinArgs &a, const PoseK &P, int64_t i, uint32_t nominee) {
-    float tx, ty, tz;
-    xform(P, a.sx[i], a.sy[i], a.sz[i], tx, ty, tz);
-    const double qx = (double)tx, qy = (double)ty, qz = (double)tz;
-    const Geom<double> &g = a.gd;
-    const PtD mA = a.means[nominee];
-    double bd;
-    uint32_t bj = nominee, bo = pt_orig(mA);
+// (the box search itself: nearest record of `means` -- (float64 distance, original index) -- inside the ball through `nominee`)
+__device__ __forceinline__ void nn_box_f64(const Geom<double> &g, const PtD *__restrict__ means, const uint32_t *__restrict__ cell_start,
+                                           double qx, double qy, double qz, uint32_t nominee, double &bd, uint32_t &bj, uint32_t &bo) {
+    const PtD mA = means[nominee];
+    bj = nominee; bo = pt_orig(mA);
     {
         const double dx = qx - mA.x, dy = qy - mA.y, dz = qz - mA.z;
         bd = (dx * dx + dy * dy) + dz * dz;                           // nn_test<double>'s expression
@@ -687,13 +693,21 @@ __device__ __forceinline__ void nn_point_fix(const LinArgs &a, const PoseK &P, i
                 const double dym = fmax(fmax(ylo_ - qy, qy - (ylo_ + g.h)) - g.slack, 0.0);
                 const bool live = y <= yh && dzm * dzm + dym * dym <= bd;
                 const uint32_t row = (uint32_t)z * plane + (uint32_t)(live ? y : yl) * unx;
-                const uint32_t s0 = a.cell_start[row + (uint32_t)xl] & g.cs_mask, e0 = a.cell_start[row + (uint32_t)xh + 1u] & g.cs_mask;
+                const uint32_t s0 = cell_start[row + (uint32_t)xl] & g.cs_mask, e0 = cell_start[row + (uint32_t)xh + 1u] & g.cs_mask;
                 s_[k] = s0; e_[k] = live ? e0 : s0;
             }
 #pragma unroll
-            for (int k = 0; k < 5; ++k) nn_scan_range<double, PtD, 0>(a.means, s_[k], e_[k], qx, qy, qz, bd, bj, bo);
+            for (int k = 0; k < 5; ++k) nn_scan_range<double, PtD, 0>(means, s_[k], e_[k], qx, qy, qz, bd, bj, bo);
         }
     }
+}
+
+__device__ __forceinline__ void nn_point_fix(const LinArgs &a, const PoseK &P, int64_t i, uint32_t nominee) {
+    float tx, ty, tz;
+    xform(P, a.sx[i], a.sy[i], a.sz[i], tx, ty, tz);
+    double bd;
+    uint32_t bj, bo;
+    nn_box_f64(a.gd, a.means, a.cell_start, (double)tx, (double)ty, (double)tz, nominee, bd, bj, bo);
     a.nn_j[i] = __builtin_sqrt(bd) < a.md_d ? bj : PCR_NONE;
 }
 

@@ -273,6 +273,13 @@ struct pcr_target {
     PtF *pts = nullptr;        // cell-sorted (the NN search reads these 16-byte records)
     PtN *pn = nullptr;         // cell-sorted point + normal records (PlaneICP gathers these); NULL = no normals
     uint64_t serial = 0;
+    // quirk Q6 (plane_icp.py:20-22: PlaneICP builds its tree on the ORIGINAL array, so a float64 target is searched in
+    // float64 while the records are gathered from the float32 copy): the float64 coordinates of the same points, in the
+    // index's cell-sorted order (w = original index), how far rounding moved any of them (metres), and the point grid's
+    // geometry in double for the float64 box search.  nullptr: a float32 target (the PCD case)
+    PtD *pts64 = nullptr;
+    double band64 = 0;
+    Geom<double> gq;
     // voxel targets
     Geom<double> gd;
     PtD *means = nullptr;      // cell-sorted
@@ -344,6 +351,7 @@ pcr_status pcr_count_nonfinite(pcr_context *ctx, const void *d_xyz, int is_f64, 
                                float *hi_out = nullptr);     // (+ the bounding box of the finite points, rounded to float32)
 pcr_status pcr_sort_scan(pcr_context *ctx, const float *d_xyz, int64_t n, unsigned flags, pcr_scan *s);
 pcr_status pcr_permute_normals(pcr_context *ctx, const float *d_in, int64_t n, const PtF *pts, PtN *out);
+pcr_status pcr_attach_points_f64(pcr_context *ctx, pcr_target *t, const double *d_xyz64);     // quirk Q6: pcr_target::pts64
 pcr_status pcr_permute_rows_f64(pcr_context *ctx, const double *d_in, int64_t n, int in_stride, const int *cols,
                                 int ncols, const PtD *means, double *out);
 

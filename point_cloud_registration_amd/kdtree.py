@@ -21,8 +21,12 @@ class KDTree:
         self.n = data.shape[0]
         self._dtype = data.dtype if data.dtype.kind == "f" else np.dtype(np.float64)
         ctx = _ctx if _ctx is not None else _capi.get_context(device)
-        # searched in float32 on the device (the PCD case)
+        # float32 data (the PCD case) is searched in float32; a float64 array is searched in float64, as every backend of
+        # the reference does with the dtype it is given (kdtree.py:18-21): float32 filter search
+        # over the index + float64 check / box search, the float64 search's neighbour in every case
         self._target = _capi.Target.points(ctx, data.astype(np.float32, copy=False))
+        if data.dtype == np.float64 and self.n > 0:
+            self._target.set_points_f64(data)
 
     def query(self, points, k=1, distance_upper_bound=np.inf):
         """Exact k nearest neighbours: ``(dist, idx)``, shape (M,) for k=1 and (M, k) otherwise."""

@@ -28,7 +28,9 @@ class PlaneICP(Registration):
         """
         target = np.asarray(target)
         self.target = target.astype(np.float32)
-        self.kdtree = KDTree(self.target, device=self._device, _ctx=self._ctx())
+        # quirk Q6 (plane_icp.py:22): the tree is built on the ORIGINAL array -- a float64 target is searched in float64
+        # (KDTree keeps the float64 coordinates beside the float32 index), the records come from the float32 copy (:20,44)
+        self.kdtree = KDTree(target if target.dtype == np.float64 else self.target, device=self._device, _ctx=self._ctx())
         if kdree is None or norm is None:
             # k-NN PCA normals on the GPU (estimate_normals.py:27-87).  They stay there: ``self.normal`` (the attribute the
             # reference sets, plane_icp.py:23-24) reads them back the first time somebody asks -- 12.7 MB over PCIe per

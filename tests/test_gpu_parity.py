@@ -978,35 +978,53 @@ def test_deeper_list_set_is_exact(capi, orc, ctx):
         assert it1 == it2 and np.array_equal(T1, T2)
 
 
-def test_quirk_q6_float64_target(capi, g9):
-    """PlaneICP.set_target with a float64 target (quirk Q6, plane_icp.py:20-22): the class casts to float32 for the
-    search AND the gather, the reference searches the float64 array.  On the fixture 82 of ~720 engineered near-ties get
-    another neighbour under the float64 tree and H moves by 2.5e-3 (tests/test_oracle_golden.py::
-    test_g9_quirk_q6_float64_target has the whole story); the HIP path must reproduce the reference's FLOAT32 tree:
-    neighbour for neighbour, H within 1e-5 of the reference class evaluated on that tree, the float64-tree reference
-    where no neighbour differs, the same pose."""
+def test_quirk_q6_float64_target(capi, orc, g9, pipeline):
+    """PlaneICP.set_target with a float64 target (quirk Q6, plane_icp.py:20-22; REPRODUCED since round 5): the reference
+    searches a tree built on the float64 array and gathers from the float32 copy.  On the fixture 82 of ~720 engineered
+    near-ties get another neighbour under the float64 tree than under a float32 one, and H moves by 2.5e-3
+    (tests/test_oracle_golden.py::test_g9_quirk_q6_float64_target has the whole story).  The HIP path -- float32 filter
+    search over the index, float64 check, float64 box search for what the bound cannot separate -- must return the
+    reference's FLOAT64-tree neighbour for every query, the reference class' own H within 1e-5 at all three poses, the
+    same final pose; ICP on the same array keeps the float32 tree (icp.py:19-20); a float32 target is untouched."""
     import point_cloud_registration_amd as pcr
     md = float(g9["max_dist"])
     p = pcr.PlaneICP(max_dist=md, k=int(g9["k"]))
     p.set_target(g9["target"], "tree", g9["plane_normals"])
     d, i = p.kdtree.query(g9["source_tie"])
-    assert np.array_equal(np.asarray(i), g9["nn_idx_f32_tree"])        # every query, the near-ties included
+    assert np.array_equal(np.asarray(i), g9["nn_idx_f64_tree"])        # every query, the near-ties included
+    assert d.dtype == np.float64 and np.allclose(d, g9["nn_dist_f64_tree"], rtol=1e-12)
     assert (g9["nn_idx_f64_tree"] != g9["nn_idx_f32_tree"]).sum() >= 50
+    # bounded queries: the float64 distance decides
+    r = float(np.median(g9["nn_dist_f64_tree"]))
+    db, ib = p.kdtree.query(g9["source_tie"], distance_upper_bound=r)
+    inside = g9["nn_dist_f64_tree"] < r
+    assert np.array_equal(np.asarray(ib)[inside], g9["nn_idx_f64_tree"][inside]) and np.all(np.asarray(ib)[~inside] == -1)
     I = np.eye(4)
+    tq = orc.TargetPoints(g9["target"], normals=g9["plane_normals"], tree_f64=True)
     for tag, T, sc in (("T", g9["T"], "source"), ("N", g9["T_near"], "source"), ("E", I, "source_tie")):
         H, g, e2 = p.calc_H_g_e2(T, g9[sc])
-        assert rel_H(H, g9[f"{tag}_plane_H_f32tree"]) < TOL_REF, tag
-        assert abs(e2 - g9[f"{tag}_plane_e2_f32tree"]) < (5 * TOL_REF if tag == "E" else 2e-3) * abs(g9[f"{tag}_plane_e2_f32tree"])
-    H, g, e2 = p.calc_H_g_e2(g9["T"], g9["source"])
-    assert rel_H(H, g9["T_plane_H"]) < TOL_REF                         # float64-tree reference, Q6 not biting
-    H, g, e2 = p.calc_H_g_e2(I, g9["source_tie"])
-    assert 1e-4 < rel_H(H, g9["E_plane_H"]) < 1e-2                     # ... and biting: the documented deviation
+        assert rel_H(H, g9[f"{tag}_plane_H"]) < TOL_REF, tag
+        assert abs(e2 - g9[f"{tag}_plane_e2"]) < (5 * TOL_REF if tag == "E" else 2e-3) * abs(g9[f"{tag}_plane_e2"])
+        Ho, go, e2o = orc.calc_H_g_e2(orc.PLANE, tq, T, g9[sc], md)
+        assert rel_H(H, Ho) < 1e-9 and abs(e2 - e2o) <= 1e-9 * abs(e2o), tag
+    out = capi.linearize(p._target, capi.Scan(capi.get_context(0), g9["source_tie"]), capi.PLANE, I, md)
+    assert capi.unpack29(out)[3] == int((g9["nn_dist_f64_tree"] < md).sum())
     # (compared where the data is: 500 m from the origin a rotation difference of 3e-7 rad moves the translation column
     # by 1.5e-4 m although no scan point moves by more than a few 1e-5 m)
     T_fin, ref = p.align(g9["source"], g9["T_near"]), g9["align_final"]
     src = g9["source"].astype(np.float64)
     moved = np.linalg.norm((src @ T_fin[:3, :3].T + T_fin[:3, 3]) - (src @ ref[:3, :3].T + ref[:3, 3]), axis=1)
     assert moved.max() < 1e-4 and _pose_close(T_fin, ref, tol=5e-4)
+    # ICP.set_target searches the float32 copy (icp.py:19-20): the float32 tree's neighbours
+    ic = pcr.ICP(max_dist=md)
+    ic.set_target(g9["target"])
+    di, ii = ic.kdtree.query(g9["source_tie"])
+    assert np.array_equal(np.asarray(ii), g9["nn_idx_f32_tree"])
+    # ... and so does PlaneICP given a float32 array: the reference class on that tree
+    p32 = pcr.PlaneICP(max_dist=md, k=int(g9["k"]))
+    p32.set_target(g9["target"].astype(np.float32), "tree", g9["plane_normals"])
+    H, g, e2 = p32.calc_H_g_e2(I, g9["source_tie"])
+    assert rel_H(H, g9["E_plane_H_f32tree"]) < TOL_REF
 
 
 @pytest.mark.parametrize("offset", [0.0, 3.0e4, 2.0e7])

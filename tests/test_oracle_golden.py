@@ -239,43 +239,53 @@ def test_g10_oracle_matches_reference_at_10m(g10, cname, vs):
 
 
 def test_g9_quirk_q6_float64_target(g9):
-    """Quirk Q6, and where the build deliberately does NOT follow it.  The reference's PlaneICP searches a tree built on
-    the ORIGINAL float64 array (plane_icp.py:22) and gathers from the float32 copy (plane_icp.py:20,44); the build
-    (oracle and HIP alike) searches AND gathers the float32 copy.  The fixture makes the difference bite: ~720 queries
-    within ~2e-5 m of the bisector plane of two target points whose coordinates (~500 m) are not
-    float32-representable -- 82 of them get a different neighbour under the float64 tree, and H moves by 2.5e-3.
-    Pinned here: (i) the neighbour the oracle returns is the REFERENCE's float32-tree neighbour for every query,
-    (ii) H, g, e2 equal the reference class evaluated on that float32 tree within the usual bars, (iii) where Q6 does
-    not bite (the ordinary scan at pose T: no neighbour differs) the float64-tree reference is matched as well,
-    (iv) the size of the deviation where it does bite is what the fixture recorded."""
+    """Quirk Q6, reproduced since round 5.  The reference's PlaneICP searches a tree built on the ORIGINAL float64 array
+    (plane_icp.py:22) and gathers from the float32 copy (plane_icp.py:20,44).  The fixture makes that bite: ~720 queries
+    within ~2e-5 m of the bisector plane of two target points whose coordinates (~500 m) are not float32-representable --
+    82 of them get a different neighbour under the float64 tree, and H moves by 2.5e-3.  Pinned here:
+    (i) with tree_f64 the oracle returns the REFERENCE's float64-tree neighbour for every query, near-ties included, and
+        H, g, e2 of the reference's own class within the usual bars at all three poses;
+    (ii) on the float32 copy (what ICP.set_target searches, icp.py:19-20) it returns the reference's float32-tree
+        neighbour for every query and the reference class evaluated on that tree;
+    (iii) the two differ where the fixture says they do (the fixture CAN fail for the reason it exists)."""
     i64, i32 = g9["nn_idx_f64_tree"], g9["nn_idx_f32_tree"]
     n_ord = int(g9["n_ordinary"])
     differ = i64 != i32
-    assert differ.sum() >= 50 and not differ[:n_ord].any()            # the fixture CAN fail for the reason it exists
+    assert differ.sum() >= 50 and not differ[:n_ord].any()            # (iii)
     t32 = g9["target"].astype(np.float32)
     md = float(g9["max_dist"])
-    tp = orc.TargetPoints(t32, normals=g9["plane_normals"])
     I = np.eye(4)
     st = orc.transform(I, g9["source_tie"])
     assert np.array_equal(st, g9["source_tie"])                        # the float32 transform is exact at the identity
+    # (i) the float64 tree
+    tq = orc.TargetPoints(g9["target"], normals=g9["plane_normals"], tree_f64=True)
+    d, i = tq.query(st)
+    db, ib = orc.nn_brute_f64(g9["target"], st)
+    assert np.array_equal(i, ib) and np.array_equal(d, db)
+    assert np.array_equal(i, i64)
+    assert np.allclose(d, g9["nn_dist_f64_tree"], rtol=1e-12)
+    for tag, T, sc in (("T", g9["T"], "source"), ("N", g9["T_near"], "source"), ("E", I, "source_tie")):
+        H, g, e2 = orc.calc_H_g_e2(orc.PLANE, tq, T, g9[sc], md)
+        assert rel_H(H, g9[f"{tag}_plane_H"]) < TOL_H, tag
+        assert np.max(np.abs(g - g9[f"{tag}_plane_g"])) < 10 * TOL_H * np.max(np.abs(g9["N_plane_g"]))
+        # e2 at poses T / N: the float32 transform itself rounds to 3e-5 m at these coordinates, in a summation order
+        # that differs between NumPy's matmul and the build's (A2) -- 1.5 % of a 2 mm residual per point
+        assert abs(e2 - g9[f"{tag}_plane_e2"]) < (5 * TOL_H if tag == "E" else 2e-3) * abs(g9[f"{tag}_plane_e2"])
+    # (ii) the float32 tree
+    tp = orc.TargetPoints(t32, normals=g9["plane_normals"])
     d, i = tp.query(st)
     db, ib = orc.nn_brute(t32, st)
     assert np.array_equal(i, ib)                                       # the oracle's grid search = exhaustive search
-    assert np.array_equal(i, i32)                                      # (i) = the reference's float32 tree, every query
+    assert np.array_equal(i, i32)
     assert np.allclose(d, g9["nn_dist_f32_tree"], rtol=1e-6)
     for tag, T, sc in (("T", g9["T"], "source"), ("N", g9["T_near"], "source"), ("E", I, "source_tie")):
         H, g, e2 = orc.calc_H_g_e2(orc.PLANE, tp, T, g9[sc], md)
-        assert rel_H(H, g9[f"{tag}_plane_H_f32tree"]) < TOL_H          # (ii)
+        assert rel_H(H, g9[f"{tag}_plane_H_f32tree"]) < TOL_H
         assert np.max(np.abs(g - g9[f"{tag}_plane_g_f32tree"])) < 10 * TOL_H * np.max(np.abs(g9["N_plane_g"]))
-        # e2 at poses T / N: the float32 transform itself rounds to 3e-5 m at these coordinates, in a summation order
-        # that differs between NumPy's matmul and the build's (A2) -- 1.5 % of a 2 mm residual per point
         assert abs(e2 - g9[f"{tag}_plane_e2_f32tree"]) < (5 * TOL_H if tag == "E" else 2e-3) * abs(g9[f"{tag}_plane_e2_f32tree"])
-    H, g, e2 = orc.calc_H_g_e2(orc.PLANE, tp, g9["T"], g9["source"], md)
-    assert rel_H(H, g9["T_plane_H"]) < TOL_H                           # (iii) float64 tree, Q6 not biting
     H, g, e2 = orc.calc_H_g_e2(orc.PLANE, tp, I, g9["source_tie"], md)
-    dev = rel_H(H, g9["E_plane_H"])                                    # (iv) float64 tree, Q6 biting
-    assert 1e-4 < dev < 1e-2, dev
-    T_fin = orc.align(orc.PLANE, tp, g9["source"], g9["T_near"], 30, 1e-3, md)
+    assert 1e-4 < rel_H(H, g9["E_plane_H"]) < 1e-2                     # (iii) what ignoring Q6 would cost on this fixture
+    T_fin = orc.align(orc.PLANE, tq, g9["source"], g9["T_near"], 30, 1e-3, md)
     # (compared where the data is: 500 m from the origin a rotation difference of 3e-7 rad moves the translation column
     # by 1.5e-4 m although no scan point moves by more than a few 1e-5 m)
     src = g9["source"].astype(np.float64)
