@@ -350,6 +350,29 @@ def main():
     pose_err = float(np.linalg.norm(T_fin[:3, 3] - T_true[:3, 3]))
     t_setup = time.perf_counter() - t_setup
 
+    # ---- the COLD numbers: what the reference's own protocol sees -- set_target on a fresh object, then
+    # ONE align (benchmark/speed_test_comparison.py:14-55).  The timed steps below run on a target that has served dozens of
+    # passes: its second list set / filter index exist (built lazily after 12 / 8 passes); a fresh target's first align never
+    # sees them.  Kernels are loaded by now, the scan is device-resident: this is the library's time, not the process start-up.
+    first_align_ms = set_target_ms = first_align_iters = None
+    if n_target <= 20_000_000:
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        if kind_name in ("icp", "plane"):
+            tgt2 = _capi.Target.points(ctx, target)
+            if kind_name == "plane":
+                tgt2.estimate_normals(15, compat=n_target <= 2_000_000, want=False)
+        else:
+            tgt2 = _capi.Target.voxels(ctx, target, voxel_size, 10)
+        ctx.synchronize()
+        set_target_ms = (time.perf_counter() - t0) * 1e3
+        sc2 = _capi.Scan(ctx, scan)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        _, first_align_iters = _capi.align(tgt2, sc2, kind, np.eye(4), 30, 1e-3, max_dist)
+        first_align_ms = (time.perf_counter() - t0) * 1e3
+        sc2.close(); tgt2.close()
+
     host_reduce = comm is not None and not comm.in_library       # fallback transport (see distributed.py)
 
     def step(k):
@@ -460,6 +483,12 @@ def main():
                        "nn_index": {"cell": info["cell"], "dims": info["dims"], "occupied_cells": info["occupied"],
                                     "halo_m": info["halo"], "halo_records": info["halo_records"]},
                        "gauss_newton_iters_to_converge": iters, "pose_error_m": round(pose_err, 6),
+                       "first_align_ms": None if first_align_ms is None else round(first_align_ms, 3),
+                       "first_align_iterations": first_align_iters,
+                       "set_target_ms": None if set_target_ms is None else round(set_target_ms, 3),
+                       "first_align_note": "fresh target (no second list set / filter index yet), one align of the device-resident "
+                                           "scan: the reference's protocol; `value` is the steady state of a target that has served "
+                                           "dozens of passes",
                        "correspondences_last_step": int(out[28]), "setup_s": round(t_setup, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,

@@ -177,11 +177,11 @@ extern "C" pcr_status pcr_context_create(int device, pcr_context **out) {
         // the values pcr_set_nn_mode accepts; anything else (1 was a search variant of round 2) -> the shipped search
         const int m = atoi(nm);
 #ifdef PCR_DEV
-        if (m == 0 || m == 2 || m == 3) ctx->nn_mode = m;
+        if (m == 0 || m == 2 || m == 3 || m == 4) ctx->nn_mode = m;
 #else
         if (m == 0 || m == 3) ctx->nn_mode = m;
 #endif
-        else fprintf(stderr, "[pcr] PCR_NN_MODE=%s is not a search mode of this library (0, 2, 3): using 0\n", nm);
+        else fprintf(stderr, "[pcr] PCR_NN_MODE=%s is not a search mode of this library (0, 3; developer build: 2, 4): using 0\n", nm);
     }
 #ifdef PCR_DEV
     const char *ff = getenv("PCR_FUSE_FINALIZE");
@@ -305,9 +305,9 @@ extern "C" pcr_status pcr_get_pipeline(pcr_context *ctx, int *variant, int *fuse
 
 extern "C" pcr_status pcr_set_nn_mode(pcr_context *ctx, int mode) {
     PCR_REQUIRE(ctx, "ctx is NULL");
-    PCR_REQUIRE(mode == 0 || mode == 2 || mode == 3, "nn mode must be 0, 2 or 3");
+    PCR_REQUIRE(mode == 0 || (mode >= 2 && mode <= 4), "nn mode must be 0, 2, 3 or 4");
 #ifndef PCR_DEV
-    PCR_REQUIRE(mode != 2, "the wave-cooperative search is in the developer build only (make DEV=1: libpcr_hip_dev.so)");
+    PCR_REQUIRE(mode != 2 && mode != 4, "the wave-cooperative searches (2: LDS-staged, 4: MFMA-filtered) are in the developer build only (make dev: libpcr_hip_dev.so)");
 #endif
     ctx->nn_mode = mode;
     return PCR_OK;

@@ -583,6 +583,20 @@ pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n,
 // gets its cost back (kernels.hip: pass_setup); a pass picks one of the two sets by how far the scan moved.
 pcr_status pcr_build_deep_lists(pcr_context *ctx, pcr_target *t) {
     if (t->is_voxel || !t->cs_h || t->n <= 0 || t->cs_h2) return PCR_OK;
+    // (an opt-out and a size cap.  PCR_DEEP_LISTS=0 never builds the set; the estimate -- copies per point scale
+    // with (1 + 2 margin)^2 on a surface: 2.3 at 0.25 cell where the first set holds n_h / n at 0.1 -- must fit PCR_DEEP_LISTS_MB,
+    // default 1/16 of the device's free memory, or the target keeps the one set)
+    {
+        const char *de = getenv("PCR_DEEP_LISTS");
+        if (de && atoi(de) == 0) return PCR_OK;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+        const char *mb = getenv("PCR_DEEP_LISTS_MB");
+        const double budget = mb && *mb ? atof(mb) * 1048576.0 : (double)free_b / 16.0;
+        const double grow = (1.0 + 2.0 * PCR_HALO2_FRAC) * (1.0 + 2.0 * PCR_HALO2_FRAC) / (1.2 * 1.2);
+        const double est = (double)(t->n_h > 0 ? t->n_h : t->n) * grow * 20.0 + 4.0 * ((double)t->gf.nx * t->gf.ny * t->gf.nz);
+        if (est > budget) return PCR_OK;
+    }
     DevBuf<uint32_t> cs_h, j_h;
     DevBuf<PtF> pts_h;
     int64_t n_h = 0;

@@ -26,6 +26,9 @@
 // entries reach 1e11 at 1e8 points, float32 would lose the 1e-5 parity bar); the 32 sums are folded
 // across the wave with a halving butterfly (32 shuffles instead of 32 x 6), then across waves through LDS.
 #include "pass_device.h"
+#ifdef PCR_DEV
+#include "nn_mfma.h"      // (round 5: the MFMA-filtered search, measured slower than k_nn_scan at every pose: developer build only)
+#endif
 
 // ---- certified reuse of the previous pass' matches ------------------------------------------------
 // Registration.align (registration.py:89-111) repeats the full search every iteration although the converged
@@ -190,6 +193,45 @@ __global__ void __launch_bounds__(256, VOXEL == 2 ? PCR_VOX_WAVES : 5) k_nn_scan
         }
     }
 }
+
+#ifdef PCR_DEV
+// Plain pass over a POINT target at a far pose: wave-cooperative search with an MFMA distance filter (nn_mfma.h); same
+// matches as k_nn_scan<0, HALO, LOCAL, PCR_NN_FULL>, bit for bit
+__global__ void __launch_bounds__(256) k_nn_bound(const LinArgs a) {
+    PoseK P;
+    if (!load_pose<false>(a, P)) return;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) nn_mfma_bound(a, a.gf, P, i);
+}
+template <int HALO, int LOCAL>
+__global__ void __launch_bounds__(256, 4) k_nn_mfma(const LinArgs a) {
+    PoseK P;
+    if (!load_pose<false>(a, P)) return;
+    __shared__ uint32_t cidx_all[4][PCR_MF_MAXC];
+    __shared__ uint32_t defer_all[4][64];
+    MfWave w;
+    w.cidx = cidx_all[threadIdx.x >> 6]; w.defer = defer_all[threadIdx.x >> 6]; w.ndefer = 0;
+    auto body = [&](int64_t first, int64_t end) { nn_tile_mfma<HALO, 1>(a, a.gf, P, w, a.pts_last, first, end); };
+    nn_tile_loop<LOCAL, 64>(a, body);
+    if (w.ndefer > 0) nn_mfma_flush<HALO>(a, a.gf, P, w);
+}
+#ifdef PCR_MF_STATS
+extern "C" __attribute__((visibility("default"))) int pcr_mf_stats_read(unsigned long long out[16], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mf_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_mf_stats), z, sizeof z) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
+static void launch_nn_mfma(bool halo, int local, dim3 grid, hipStream_t st, const LinArgs &a) {
+    const dim3 block(256);
+    {   // the bounds first: a streaming launch over the scan
+        int64_t nb = (a.n + 255) / 256;
+        if (nb > 256 * 16) nb = 256 * 16;
+        hipLaunchKernelGGL(k_nn_bound, dim3((unsigned)(nb > 0 ? nb : 1)), block, 0, st, a);
+    }
+    if (halo) { if (local == 1) hipLaunchKernelGGL((k_nn_mfma<1, 1>), grid, block, 0, st, a); else hipLaunchKernelGGL((k_nn_mfma<1, 0>), grid, block, 0, st, a); }
+    else { if (local == 1) hipLaunchKernelGGL((k_nn_mfma<0, 1>), grid, block, 0, st, a); else hipLaunchKernelGGL((k_nn_mfma<0, 0>), grid, block, 0, st, a); }
+}
+#endif
 
 // Plain pass over a voxel target that has a float32 filter index (pass_device.h: nn_point_filter)
 // (Two-way settling inside this kernel -- nn_point_filter<HALO, 1>: the search also tracks the runner-up and a third bound,
@@ -496,6 +538,13 @@ pcr_status pcr_ensure_scratch(pcr_context *ctx, int64_t n_points) {
         const size_t ctr_words = 9 * 16 + (size_t)PCR_TILE_CTRS * PCR_TILE_STRIDE + 16;
         HIP_TRY(pcr_malloc_retry((void **)&ctx->d_tile_ctr, sizeof(uint32_t) * ctr_words));
         HIP_TRY(hipMemsetAsync(ctx->d_tile_ctr, 0, sizeof(uint32_t) * ctr_words, ctx->stream));
+#ifdef PCR_DEV
+        {
+            int nbm = 0;
+            const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbm, k_nn_mfma<1, 0>, 256, 0);
+            ctx->nn_blocks_per_cu[4] = (e == hipSuccess && nbm > 0) ? nbm : 2;
+        }
+#endif
         for (int v = 0; v < 4; ++v) {
             int nb = 0;
             if (v == 2) {
@@ -586,10 +635,11 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
         return nb < 8 ? 8 : nb;
     }();
     ps->reuse_ready = false;
-    if (!one_kernel && !q6 && ctx->reuse != 0 && (ctx->nn_mode == 0 || ctx->nn_mode == 3) && s->n > 0) {
-        if (!s->lb2) {
+    const bool nn_plain = ctx->nn_mode == 0 || ctx->nn_mode == 4;     // (4, developer build: plain searches run the MFMA-filtered kernel)
+    if (!one_kernel && !q6 && ctx->reuse != 0 && (nn_plain || ctx->nn_mode == 3) && s->n > 0) {
+        if (!s->lb2 || !s->umask) {
             const size_t words = (((size_t)s->n + 63) / 64 + 31) & ~(size_t)15;     // whole 16-word chunks + slack
-            HIP_TRY(pcr_scan_alloc(s, (void **)&s->lb2, sizeof(float) * (size_t)s->n));
+            if (!s->lb2) HIP_TRY(pcr_scan_alloc(s, (void **)&s->lb2, sizeof(float) * (size_t)s->n));
             HIP_TRY(pcr_scan_alloc(s, (void **)&s->umask, sizeof(unsigned long long) * words));
             HIP_TRY(hipMemsetAsync(s->umask, 0, sizeof(unsigned long long) * words, ctx->stream));
             s->track_valid = false;
@@ -602,11 +652,18 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
         }
         ps->reuse_ready = true;
     }
+    // the MFMA-filtered search (developer build) keeps its per-point bounds in lb2 (dead between passes unless the previous one
+    // was a tracking pass, and a full search invalidates those anyway)
+    if (!one_kernel && !q6 && !t->is_voxel && ctx->nn_mode == 4 && !s->lb2 && s->n > 0) {
+        HIP_TRY(pcr_scan_alloc(s, (void **)&s->lb2, sizeof(float) * (size_t)s->n));
+        s->track_valid = false;
+    }
     ps->ctx = ctx; ps->t = t; ps->s = s; ps->kind = kind; ps->one_kernel = one_kernel; ps->q6 = q6;
     LinArgs &a = ps->a;
     memset(&a, 0, sizeof a);
     a.sx = s->x; a.sy = s->y; a.sz = s->z; a.n = s->n;
     a.gf = t->gf; a.pts = t->pts; a.pn = t->pn;
+    a.pts_last = (uint32_t)(t->is_voxel ? 0 : t->n + PCR_PTS_PAD - 1);
     a.gd = t->gd; a.means = t->means; a.vnorm = t->vnorm; a.vicov = t->vicov;
     a.cell_start = t->cell_start;
     // The filter index is built by the first pass that gets its cost back: a search + reduce pass at once; the fused
@@ -639,7 +696,7 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
     }
     // the deeper set of extended lists of a point target: built once the target has served PCR_HALO2_AFTER search + reduce
     // passes (a failed build is not an error: the pass runs on the first set)
-    if (!t->is_voxel && !one_kernel && !q6 && t->cs_h && ctx->nn_mode == 0) {
+    if (!t->is_voxel && !one_kernel && !q6 && t->cs_h && nn_plain) {
         if (!t->deep_tried && ++t->split_passes > PCR_HALO2_AFTER) {
             t->deep_tried = true;
             if (pcr_build_deep_lists(ctx, t) != PCR_OK) (void)hipGetLastError();
@@ -821,8 +878,16 @@ static pcr_status pass_enqueue(Pass *ps) {
             if (ctx->tile_local >= 0) local = ctx->tile_local;
             ps->a.sched_local = local;
 #ifdef PCR_DEV
+            // (developer build, nn_mode 4: the MFMA-filtered search on every plain full search of a point target)
+            const bool mfma = !vox && !ps->q6 && mode == PCR_NN_FULL && ps->t->n > 0 && ctx->nn_mode == 4;
             if (!vox && !ps->q6 && ctx->nn_mode == 2) {
                 pcr_dev_launch_coop(nn_grid, ctx->stream, a);
+            } else if (mfma) {
+                int64_t nbm = (int64_t)ctx->num_cu * ctx->nn_blocks_per_cu[4];
+                if (nbm > need) nbm = need;
+                nbm = (nbm + 7) & ~(int64_t)7;
+                if (nbm < 8) nbm = 8;
+                launch_nn_mfma(ps->t->cs_h != nullptr, ps->a.sched_local == 1 ? 1 : 0, dim3((unsigned)nbm), ctx->stream, a);
             } else
 #endif
             if (!vox && !ps->q6) {

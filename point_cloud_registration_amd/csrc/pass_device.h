@@ -26,6 +26,7 @@ struct LinArgs {
     // point target
     Geom<float> gf;
     const PtF *pts;
+    uint32_t pts_last;               // index of the last readable record of pts (its sentinels included)
     const PtN *pn;
     // voxel target
     Geom<double> gd;

@@ -207,7 +207,8 @@ struct pcr_context {
     double *d_trace = nullptr;
     int trace_cap = 0;
     int variant = 0;
-    int nn_mode = 0;             // 0 per-lane search; 2 wave-cooperative (developer builds); 3 = 0 without the float32 filter of the centroid search
+    int nn_mode = 0;             // 0 per-lane search; 2 wave-cooperative, LDS-staged (developer builds); 3 = 0 without the float32 filter of the
+                                 // centroid search; 4 = wave-cooperative with an MFMA distance filter (developer builds, round 5)
     // certified reuse of the previous pass' matches (see kernels.hip: choose_nn_mode)
     double local_frac = 0.35;    // block-local tile hand-out when the scan moved less than this x cell size (PCR_LOCAL_FRAC)
     double voxel_cell_mult = 2.0; // PCR_VOXEL_CELL_MULT: centroid grid cell edge in voxels
@@ -221,7 +222,7 @@ struct pcr_context {
     uint64_t next_serial = 1;    // targets get unique serial numbers (validity of a scan's previous matches)
     bool fuse_finalize = true;   // k_reduce_finalize (PCR_FUSE_FINALIZE=0: k_reduce + k_finalize)
     uint32_t *d_tile_ctr = nullptr;     // per-XCD dynamic tile counters of k_nn_scan
-    int nn_blocks_per_cu[4] = {4, 4, 4, 4};   // resident 256-thread blocks per CU of k_nn_scan<0/1>, k_nn_coop, k_nn_filter
+    int nn_blocks_per_cu[5] = {4, 4, 4, 4, 2};   // resident 256-thread blocks per CU of k_nn_scan<0/1>, k_nn_coop, k_nn_filter, k_nn_mfma
     uint32_t filter_stamp = 0;          // stamp of the last k_nn_filter pass (k_nn_fix)
     // profiling
     bool prof_on = false;

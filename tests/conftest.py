@@ -105,6 +105,7 @@ PIPELINES = {
     "split": dict(variant=1, fuse_finalize=1, nn_mode=0, reuse=1),      # k_nn_scan + k_reduce_finalize (what large scans run)
     "reuse": dict(variant=1, fuse_finalize=1, nn_mode=0, reuse=2),      # ... certified reuse of the previous matches FORCED on every pass it can run on
     "noreuse": dict(variant=1, fuse_finalize=1, nn_mode=0, reuse=0),    # ... and off
+    "mfma": dict(variant=1, fuse_finalize=1, nn_mode=4, reuse=1),       # wave-cooperative search with an MFMA distance filter (k_nn_mfma, round 5)
     "coop": dict(variant=1, fuse_finalize=1, nn_mode=2, reuse=1),       # wave-cooperative search (k_nn_coop)
     "nofilter": dict(variant=1, fuse_finalize=1, nn_mode=3, reuse=1),   # centroid searches in float64 throughout (no float32 filter + check)
     "unfused": dict(variant=1, fuse_finalize=0, nn_mode=0, reuse=2),    # k_nn_scan + k_reduce + k_finalize
@@ -116,7 +117,7 @@ PIPELINES = {
 # pipelines that need the developer kernels of csrc/kernels_dev.hip: only libpcr_hip_dev.so (`make dev`) has them.  The
 # shipped library runs the others; tests/test_gpu_dev_build.py re-runs every pipeline test in a process that loaded the
 # developer build (PCR_LIB).
-DEV_PIPELINES = ("coop", "unfused", "onekernel_unfused")
+DEV_PIPELINES = ("coop", "mfma", "unfused", "onekernel_unfused")
 
 
 @pytest.fixture(params=list(PIPELINES))

@@ -25,12 +25,14 @@ def test_shipped_library_has_no_developer_kernels():
     with pytest.raises(ValueError):
         ctx.set_nn_mode(2)                       # wave-cooperative search: developer build only
     with pytest.raises(ValueError):
+        ctx.set_nn_mode(4)                       # ... and its MFMA-filtered relative (round 5)
+    with pytest.raises(ValueError):
         ctx.set_fuse_finalize(0)                 # unfused folds: developer build only
     assert ctx.get_pipeline() == before
     out = subprocess.run(["nm", "-D", "--defined-only", _capi.LIB_PATH], check=True, capture_output=True, text=True).stdout
     assert "k_nn_coop" not in out and "pcr_dev_" not in out
     data = open(_capi.LIB_PATH, "rb").read()
-    for name in (b"k_nn_coop", b"k_nn_counters", b"10k_finalize", b"8k_nn_fix"):
+    for name in (b"k_nn_coop", b"k_nn_mfma", b"k_nn_bound", b"k_nn_counters", b"10k_finalize", b"8k_nn_fix"):
         assert name not in data, name          # not even as device code in the fat binary
 
 

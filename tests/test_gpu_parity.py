@@ -403,6 +403,7 @@ def test_profile_counters(capi, ctx, g2, pipeline):
             "reuse": dict(nn=5, reduce=5, finalize=0, linearize=0, certify=3),     # full, tracking, 3 x certify + list
             "noreuse": dict(nn=5, reduce=5, finalize=0, linearize=0, certify=0),
             "coop": dict(nn=5, reduce=5, finalize=0, linearize=0),
+            "mfma": dict(nn=5, reduce=5, finalize=0, linearize=0),
             "nofilter": dict(nn=5, reduce=5, finalize=0, linearize=0),
             "unfused": dict(nn=5, reduce=5, finalize=5, linearize=0, certify=3),
             "onekernel": dict(nn=0, reduce=0, finalize=0, linearize=5),
