@@ -247,16 +247,20 @@ PCR_API pcr_status pcr_set_variant(pcr_context *ctx, int variant);
 PCR_API pcr_status pcr_get_variant(pcr_context *ctx, int *variant);
 /* NN search kernel of variant 1: 0 = per-lane ring search (shipped; plain passes over a voxel target run a float32 filter
  * search over the rounded centroids and check its winner in float64 -- results identical to the float64 search),
- * 2 = wave-cooperative LDS-staged search, 3 = as 0 with the centroid search in float64 throughout (A/B, tests) */
+ * 2 = wave-cooperative LDS-staged search, 3 = as 0 with the centroid search in float64 throughout (A/B, tests),
+ * 4 = wave-cooperative search with an MFMA distance filter (round 5); 2 and 4: developer build only                */
 PCR_API pcr_status pcr_set_nn_mode(pcr_context *ctx, int mode);
 /* Certified reuse of the previous pass' matches (no reference counterpart: Registration.align,
  * registration.py:89-111, searches afresh every iteration).  When consecutive passes over one scan and target
  * differ by a small pose change, a pass first proves -- per point, by the triangle inequality on a bound the
  * previous search recorded -- that the old match is still the exact nearest neighbour, and searches only the
  * points where the proof fails.  The correspondences, and therefore all 29 sums, are bit-identical to a full
- * search; only the time changes.  mode: 0 = off, 1 = automatic (default: tried when the scan's typical
- * displacement since the last pass is below tau x cell size of the target's index), 2 = always.  mu = how far
- * beyond its match a tracking search looks, x cell size.  tau / mu <= 0 keep the current value.          */
+ * search; only the time changes.  mode: 0 = off (the DEFAULT since round 5: at the reference's tol = 1e-3 a Gauss-Newton
+ * run stops as soon as its steps reach millimetres, the automatic policy never engaged on a BASELINE config, and the state
+ * costs 4 bytes per scan point -- opt in for tight tolerances / re-evaluation in place, where it pays 1.2-2.6x), 1 =
+ * automatic (tried when the scan's typical displacement since the last pass is below tau x cell size of the target's
+ * index), 2 = always.  mu = how far beyond its match a tracking search looks, x cell size.  tau / mu <= 0 keep the
+ * current value.  PCR_REUSE in the environment sets the mode of new contexts.                                          */
 PCR_API pcr_status pcr_set_reuse(pcr_context *ctx, int mode, double tau, double mu);
 PCR_API pcr_status pcr_get_reuse(pcr_context *ctx, int *mode, double *tau, double *mu);
 /* out[0..2] = passes over this scan by search mode (full, tracking, certify + list); out[3] / out[4] = points

@@ -237,7 +237,7 @@ class Context:
         check(lib().pcr_set_fuse_finalize(self.handle, int(bool(on))))
 
     def set_reuse(self, mode=None, tau=0.0, mu=0.0):
-        """Certified reuse of the previous pass' matches: 0 off, 1 automatic (default), 2 always; ``tau`` / ``mu``
+        """Certified reuse of the previous pass' matches: 0 off (default), 1 automatic, 2 always; ``tau`` / ``mu``
         in units of the target index' cell size (<= 0 keeps the current value)."""
         if mode is None:
             mode = self.get_reuse()["mode"]

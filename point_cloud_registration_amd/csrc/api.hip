@@ -209,7 +209,7 @@ extern "C" pcr_status pcr_context_create(int device, pcr_context **out) {
     if (rt && *rt) ctx->reuse_tau = atof(rt);
     const char *rm = getenv("PCR_REUSE_MU");
     if (rm && *rm) ctx->reuse_mu = atof(rm);
-    if (ctx->reuse < 0 || ctx->reuse > 2) ctx->reuse = 1;
+    if (ctx->reuse < 0 || ctx->reuse > 2) ctx->reuse = 0;
     const char *cl = getenv("PCR_CACHE_LIMIT_MB");
     if (cl && *cl && atof(cl) >= 0) ctx->cache_limit = (size_t)(atof(cl) * 1048576.0);
     *out = ctx;

@@ -26,6 +26,56 @@ struct KnnList {
     __device__ __forceinline__ float &D(int s) { return d[s * KNN_BLOCK + lane]; }
     __device__ __forceinline__ uint32_t &J(int s) { return j[s * KNN_BLOCK + lane]; }
     __device__ __forceinline__ uint32_t O(int s) { return pt_orig(pts[j[s * KNN_BLOCK + lane]]); }
+    __device__ __forceinline__ void offer(float dist2, uint32_t jj, uint32_t oo, float &kth, uint32_t &kth_o);
+    template <typename F>
+    __device__ __forceinline__ void for_each(F &&f) { for (int s = 0; s < cnt; ++s) f(s, D(s), J(s)); }
+};
+
+// Round 5: the list in REGISTERS for k <= 16 (the reference's default is 15, plane_icp.py:14).  The LDS
+// list costs a chain of dependent LDS round trips per accepted candidate (read slot, compare, write slot, next) -- and a wave
+// runs that chain whenever ANY of its lanes accepts, i.e. for nearly every candidate -- and caps the CU at 20 one-wave blocks.
+// Here an insertion is straight-line: the list is sorted, so "new < slot s" is monotone in s and every slot takes either itself,
+// the new element, or its predecessor -- 16 x (compare + 4 selects), no memory.  Ties (equal float32 distances) are ordered by
+// the ORIGINAL index, read from the records only when two distances are equal.
+#define KNN_REG_K 16
+struct KnnReg {
+    float d[KNN_REG_K];
+    uint32_t j[KNN_REG_K];
+    const PtF *pts;
+    int k, cnt;
+    __device__ __forceinline__ void init(int k_, const PtF *pts_) {
+        k = k_; cnt = 0; pts = pts_;
+#pragma unroll
+        for (int s = 0; s < KNN_REG_K; ++s) { d[s] = __int_as_float(0x7f800000); j[s] = PCR_NONE; }
+    }
+    template <typename F>
+    __device__ __forceinline__ void for_each(F &&f) const {            // nearest first
+#pragma unroll
+        for (int s = 0; s < KNN_REG_K; ++s) if (s < cnt) f(s, d[s], j[s]);
+    }
+    __device__ __forceinline__ void offer(float dist2, uint32_t jj, uint32_t oo, float &kth, uint32_t &kth_o) {
+        if (cnt == k) {
+            bool acc = dist2 < kth;
+            if (dist2 == kth) acc = oo < pt_orig(pts[kth_o]);
+            if (!acc) return;
+        }
+        float cd = dist2;                 // carried element: the new one until it is placed, then the slot's old content
+        uint32_t cj = jj;
+#pragma unroll
+        for (int s = 0; s < KNN_REG_K; ++s) {
+            const float ds = d[s];
+            const uint32_t js = j[s];
+            bool ins = dist2 < ds;
+            if (dist2 == ds && js != PCR_NONE) ins = oo < pt_orig(pts[js]);      // (an exact tie: the smaller original index first)
+            d[s] = ins ? cd : ds; j[s] = ins ? cj : js;
+            cd = ins ? ds : cd; cj = ins ? js : cj;
+        }
+        if (cnt < k) ++cnt;
+        if (cnt == k) {
+#pragma unroll
+            for (int s = 0; s < KNN_REG_K; ++s) if (s == k - 1) { kth = d[s]; kth_o = j[s]; }
+        }
+    }
 };
 
 __device__ __forceinline__ void knn_offer(KnnList &L, float dist2, uint32_t jj, uint32_t oo, float &kth, uint32_t &kth_o) {
@@ -43,6 +93,10 @@ __device__ __forceinline__ void knn_offer(KnnList &L, float dist2, uint32_t jj, 
     if (L.cnt == L.k) { kth = L.D(L.k - 1); kth_o = L.J(L.k - 1); }
 }
 
+__device__ __forceinline__ void KnnList::offer(float dist2, uint32_t jj, uint32_t oo, float &kth, uint32_t &kth_o) {
+    knn_offer(*this, dist2, jj, oo, kth, kth_o);
+}
+
 // Candidates are fetched KNN_BATCH at a time (independent loads in flight before the first compare: the search is a chain
 // of dependent round trips, one per candidate before round 4 -- k_knn_normals 1.49 ms per 1.06 M points at 5 % of the VALU
 // rate).  A batch may read past the end of the range: those records exist (the array carries PCR_PTS_PAD sentinels behind
@@ -51,7 +105,8 @@ __device__ __forceinline__ void knn_offer(KnnList &L, float dist2, uint32_t jj, 
 #ifndef KNN_BATCH
 #define KNN_BATCH 4
 #endif
-__device__ __forceinline__ void knn_scan_range(KnnList &L, const PtF *__restrict__ pts, uint32_t s, uint32_t e,
+template <typename LIST>
+__device__ __forceinline__ void knn_scan_range(LIST &L, const PtF *__restrict__ pts, uint32_t s, uint32_t e,
                                                float qx, float qy, float qz, float &kth, uint32_t &kth_o) {
     for (uint32_t j = s; j < e; j += KNN_BATCH) {
         PtF p[KNN_BATCH];
@@ -62,14 +117,15 @@ __device__ __forceinline__ void knn_scan_range(KnnList &L, const PtF *__restrict
             if (j + u < e) {
                 const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
                 const float d = dist2_f32(dx, dy, dz);
-                knn_offer(L, d, j + u, pt_orig(p[u]), kth, kth_o);
+                L.offer(d, j + u, pt_orig(p[u]), kth, kth_o);
             }
         }
     }
 }
 
+template <typename LIST>
 __device__ __forceinline__ void knn_search(const Geom<float> &g, const PtF *__restrict__ pts,
-                                           const uint32_t *__restrict__ cs, float qx, float qy, float qz, KnnList &L) {
+                                           const uint32_t *__restrict__ cs, float qx, float qy, float qz, LIST &L) {
     const float INF = __int_as_float(0x7f800000);
     float kth = INF;
     uint32_t kth_o = PCR_NONE;
@@ -139,27 +195,36 @@ __device__ __forceinline__ KnnList knn_list(int k) {
     return L;
 }
 
+template <typename LIST>
+__device__ __forceinline__ void knn_query_body(const Geom<float> &g, const PtF *pts, const uint32_t *cs, int64_t n_target,
+                                               const float *q, int64_t i, int k, float *dist, int64_t *idx, LIST &L) {
+    knn_search(g, pts, cs, q[3 * i], q[3 * i + 1], q[3 * i + 2], L);
+    for (int s = L.cnt; s < k; ++s) { dist[i * k + s] = __int_as_float(0x7f800000); idx[i * k + s] = n_target; }
+    L.for_each([&](int s, float ds, uint32_t js) {
+        dist[i * k + s] = __builtin_sqrtf(ds);
+        idx[i * k + s] = (int64_t)pt_orig(pts[js]);
+    });
+}
+
+template <int REG>
 __global__ void __launch_bounds__(KNN_BLOCK) k_knn_query(Geom<float> g, const PtF *pts, const uint32_t *cs, int64_t n_target,
                                                          const float *q, int64_t m, int k, float *dist, int64_t *idx) {
     const int64_t i = (int64_t)blockIdx.x * KNN_BLOCK + threadIdx.x;
     if (i >= m) return;
-    KnnList L = knn_list(k);
-    L.pts = pts;
-    knn_search(g, pts, cs, q[3 * i], q[3 * i + 1], q[3 * i + 2], L);
-    for (int s = 0; s < k; ++s) {
-        const bool have = s < L.cnt;
-        dist[i * k + s] = have ? __builtin_sqrtf(L.D(s)) : __int_as_float(0x7f800000);
-        idx[i * k + s] = have ? (int64_t)L.O(s) : n_target;
+    if (REG) {
+        KnnReg L;
+        L.init(k, pts);
+        knn_query_body(g, pts, cs, n_target, q, i, k, dist, idx, L);
+    } else {
+        KnnList L = knn_list(k);
+        L.pts = pts;
+        knn_query_body(g, pts, cs, n_target, q, i, k, dist, idx, L);
     }
 }
 
-// normals of the target's own points, processed (and written) in cell-sorted order
-__global__ void __launch_bounds__(KNN_BLOCK) k_knn_normals(Geom<float> g, const PtF *pts, const uint32_t *cs, int64_t n,
-                                                           int k, int compat, PtN *pn) {
-    const int64_t i = (int64_t)blockIdx.x * KNN_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    KnnList L = knn_list(k);
-    L.pts = pts;
+template <typename LIST>
+__device__ __forceinline__ void knn_normals_body(const Geom<float> &g, const PtF *pts, const uint32_t *cs, int64_t i,
+                                                 int k, int compat, PtN *pn, LIST &L) {
     const PtF me = pts[i];
     knn_search(g, pts, cs, me.x, me.y, me.z, L);
     double c[6];
@@ -167,27 +232,27 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn_normals(Geom<float> g, const 
         // estimate_normals.py:56-72: float32 running sums over the neighbours (nearest first),
         // cov = E[pp^T] - mu mu^T in float32
         float sx = 0, sy = 0, sz = 0, xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
-        for (int s = 0; s < L.cnt; ++s) {
-            const PtF p = pts[L.J(s)];
+        L.for_each([&](int, float, uint32_t js) {
+            const PtF p = pts[js];
             sx += p.x; sy += p.y; sz += p.z;
             xx += p.x * p.x; xy += p.x * p.y; xz += p.x * p.z; yy += p.y * p.y; yz += p.y * p.z; zz += p.z * p.z;
-        }
+        });
         const float kf = (float)k;
         const float mx = sx / kf, my = sy / kf, mz = sz / kf;
         c[0] = xx / kf - mx * mx; c[1] = xy / kf - mx * my; c[2] = xz / kf - mx * mz;
         c[3] = yy / kf - my * my; c[4] = yz / kf - my * mz; c[5] = zz / kf - mz * mz;
     } else {
         double mx = 0, my = 0, mz = 0;
-        for (int s = 0; s < L.cnt; ++s) { const PtF p = pts[L.J(s)]; mx += p.x; my += p.y; mz += p.z; }
+        L.for_each([&](int, float, uint32_t js) { const PtF p = pts[js]; mx += p.x; my += p.y; mz += p.z; });
         const double kd = (double)(L.cnt > 0 ? L.cnt : 1);
         mx /= kd; my /= kd; mz /= kd;
 #pragma unroll
         for (int a = 0; a < 6; ++a) c[a] = 0;
-        for (int s = 0; s < L.cnt; ++s) {
-            const PtF p = pts[L.J(s)];
+        L.for_each([&](int, float, uint32_t js) {
+            const PtF p = pts[js];
             const double dx = p.x - mx, dy = p.y - my, dz = p.z - mz;
             c[0] += dx * dx; c[1] += dx * dy; c[2] += dx * dz; c[3] += dy * dy; c[4] += dy * dz; c[5] += dz * dz;
-        }
+        });
 #pragma unroll
         for (int a = 0; a < 6; ++a) c[a] /= kd;
     }
@@ -197,6 +262,29 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn_normals(Geom<float> g, const 
     r.x = me.x; r.y = me.y; r.z = me.z; r.orig = pt_orig(me);
     r.nx = (float)nv[0]; r.ny = (float)nv[1]; r.nz = (float)nv[2]; r.pad = 0;
     pn[i] = r;
+}
+
+// normals of the target's own points, processed (and written) in cell-sorted order
+template <int REG>
+__global__ void __launch_bounds__(KNN_BLOCK) k_knn_normals(Geom<float> g, const PtF *pts, const uint32_t *cs, int64_t n,
+                                                           int k, int compat, PtN *pn) {
+    const int64_t i = (int64_t)blockIdx.x * KNN_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    if (REG) {
+        KnnReg L;
+        L.init(k, pts);
+        knn_normals_body(g, pts, cs, i, k, compat, pn, L);
+    } else {
+        KnnList L = knn_list(k);
+        L.pts = pts;
+        knn_normals_body(g, pts, cs, i, k, compat, pn, L);
+    }
+}
+
+// k <= 16: the register list (PCR_KNN_REG=0: the LDS list for every k, for A/B)
+static bool knn_use_registers(int k) {
+    static const int allow = getenv("PCR_KNN_REG") ? atoi(getenv("PCR_KNN_REG")) : 1;
+    return allow != 0 && k <= KNN_REG_K;
 }
 
 static pcr_status check_k(int k) {
@@ -219,8 +307,13 @@ extern "C" pcr_status pcr_knn_query(pcr_target *t, const float *q, int64_t m, in
     HIP_TRY(d_idx.alloc((size_t)m * k));
     HIP_TRY(hipMemcpyAsync(d_q.p, q, 12 * (size_t)m, hipMemcpyHostToDevice, ctx->stream));
     const size_t smem = 2 * sizeof(float) * (size_t)k * KNN_BLOCK;
-    hipLaunchKernelGGL(k_knn_query, dim3((unsigned)((m + KNN_BLOCK - 1) / KNN_BLOCK)), dim3(KNN_BLOCK), smem, ctx->stream,
-                       t->gf, t->pts, t->cell_start, t->n, (const float *)d_q.p, m, k, d_dist.p, d_idx.p);
+    const dim3 qgrid((unsigned)((m + KNN_BLOCK - 1) / KNN_BLOCK));
+    if (knn_use_registers(k))
+        hipLaunchKernelGGL(k_knn_query<1>, qgrid, dim3(KNN_BLOCK), 0, ctx->stream,
+                           t->gf, t->pts, t->cell_start, t->n, (const float *)d_q.p, m, k, d_dist.p, d_idx.p);
+    else
+        hipLaunchKernelGGL(k_knn_query<0>, qgrid, dim3(KNN_BLOCK), smem, ctx->stream,
+                           t->gf, t->pts, t->cell_start, t->n, (const float *)d_q.p, m, k, d_dist.p, d_idx.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(dist, d_dist.p, 4 * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(idx, d_idx.p, 8 * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));
@@ -237,8 +330,11 @@ extern "C" pcr_status pcr_target_estimate_normals(pcr_target *t, int k, int comp
     if (!t->pn) HIP_TRY(pcr_persist_alloc((void **)&t->pn, sizeof(PtN) * (size_t)(t->n ? t->n : 1)));
     if (t->n > 0) {
         const size_t smem = 2 * sizeof(float) * (size_t)k * KNN_BLOCK;
-        hipLaunchKernelGGL(k_knn_normals, dim3((unsigned)((t->n + KNN_BLOCK - 1) / KNN_BLOCK)), dim3(KNN_BLOCK), smem,
-                           ctx->stream, t->gf, t->pts, t->cell_start, t->n, k, compat, t->pn);
+        const dim3 ngrid((unsigned)((t->n + KNN_BLOCK - 1) / KNN_BLOCK));
+        if (knn_use_registers(k))
+            hipLaunchKernelGGL(k_knn_normals<1>, ngrid, dim3(KNN_BLOCK), 0, ctx->stream, t->gf, t->pts, t->cell_start, t->n, k, compat, t->pn);
+        else
+            hipLaunchKernelGGL(k_knn_normals<0>, ngrid, dim3(KNN_BLOCK), smem, ctx->stream, t->gf, t->pts, t->cell_start, t->n, k, compat, t->pn);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }

@@ -256,41 +256,57 @@ __device__ __forceinline__ void accumulate(double *acc, const LinArgs &a, const 
 // gathered before either is accumulated (two independent 16/32-byte gathers in flight per lane: at
 // 1e8 target points every gather is an HBM miss and the kernel is bound by misses in flight); the
 // points are still accumulated in index order, so the sums are bit-identical to the one-at-a-time loop.
+// Round 5, measured and NOT kept: FOUR CONSECUTIVE scan points per lane (index and coordinates as 16-byte
+// loads, four gathers in flight) is slower -- 24.9 vs 20.8 us at 1.06 M points, 150 vs 117 / 351 vs 270 us at 1e8 -- because a
+// wave-level gather then covers every 4th of 256 points instead of 64 neighbours: ~3x the distinct lines per instruction, and
+// the L1 tag rate is what gathers pay with (docs/EXPERIMENTS.md).  PCR_RED_W selects how many scan points' gathers a lane has in
+// flight in the neighbour-preserving mapping below (lane l of a tile = point l of 64 consecutive ones).
+#ifndef PCR_RED_W
+#define PCR_RED_W 2
+#endif
+#ifndef PCR_RED_NT
+#define PCR_RED_NT 0
+#endif
+template <typename T>
+__device__ __forceinline__ T stream_load(const T *p) {
+#if PCR_RED_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 template <int KIND>
 __device__ __forceinline__ void reduce_stream(double *acc, const LinArgs &a, const PoseK &P, int64_t base, int64_t end,
                                               int64_t stride) {
     if (KIND == PCR_ICP || KIND == PCR_PLANE) {
-        for (int64_t i = base; i < end; i += 2 * stride) {
-            const int64_t i1 = i + stride;
-            const bool two = i1 < end;
-            const uint32_t j0 = a.nn_j[i];
-            const uint32_t j1 = two ? a.nn_j[i1] : PCR_NONE;
-            const bool ok0 = j0 != PCR_NONE, ok1 = j1 != PCR_NONE;
-            float4 q0 = make_float4(0, 0, 0, 0), n0 = q0, q1 = q0, n1 = q0;
-            if (KIND == PCR_PLANE) {
-                if (ok0) { const float4 *r = reinterpret_cast<const float4 *>(a.pn + j0); q0 = r[0]; n0 = r[1]; }
-                if (ok1) { const float4 *r = reinterpret_cast<const float4 *>(a.pn + j1); q1 = r[0]; n1 = r[1]; }
-            } else {
-                if (ok0) q0 = a.pts[j0];
-                if (ok1) q1 = a.pts[j1];
+        constexpr int W = PCR_RED_W;
+        for (int64_t i = base; i < end; i += W * stride) {
+            uint32_t j[W];
+            float4 q[W], nr[W];
+#pragma unroll
+            for (int u = 0; u < W; ++u) {
+                const int64_t iu = i + u * stride;
+                j[u] = iu < end ? stream_load(a.nn_j + iu) : PCR_NONE;
             }
-            if (ok0) {
-                const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
-                float tx, ty, tz;
-                xform(P, x, y, z, tx, ty, tz);
-                const float dx = tx - q0.x, dy = ty - q0.y, dz = tz - q0.z;
-                if (gate_f32(a, dx, dy, dz)) {
-                    if (KIND == PCR_PLANE) acc_plane(acc, P, x, y, z, n0.x, n0.y, n0.z, (double)dx, (double)dy, (double)dz);
-                    else acc_icp(acc, P, a.flags, x, y, z, (double)dx, (double)dy, (double)dz);
+#pragma unroll
+            for (int u = 0; u < W; ++u) {
+                q[u] = make_float4(0, 0, 0, 0); nr[u] = q[u];
+                if (j[u] != PCR_NONE) {
+                    if (KIND == PCR_PLANE) { const float4 *r = reinterpret_cast<const float4 *>(a.pn + j[u]); q[u] = r[0]; nr[u] = r[1]; }
+                    else q[u] = a.pts[j[u]];
                 }
             }
-            if (ok1) {
-                const float x = a.sx[i1], y = a.sy[i1], z = a.sz[i1];
+#pragma unroll
+            for (int u = 0; u < W; ++u) {
+                if (j[u] == PCR_NONE) continue;
+                const int64_t iu = i + u * stride;
+                const float x = stream_load(a.sx + iu), y = stream_load(a.sy + iu), z = stream_load(a.sz + iu);
                 float tx, ty, tz;
                 xform(P, x, y, z, tx, ty, tz);
-                const float dx = tx - q1.x, dy = ty - q1.y, dz = tz - q1.z;
+                const float dx = tx - q[u].x, dy = ty - q[u].y, dz = tz - q[u].z;
                 if (gate_f32(a, dx, dy, dz)) {
-                    if (KIND == PCR_PLANE) acc_plane(acc, P, x, y, z, n1.x, n1.y, n1.z, (double)dx, (double)dy, (double)dz);
+                    if (KIND == PCR_PLANE) acc_plane(acc, P, x, y, z, nr[u].x, nr[u].y, nr[u].z, (double)dx, (double)dy, (double)dz);
                     else acc_icp(acc, P, a.flags, x, y, z, (double)dx, (double)dy, (double)dz);
                 }
             }

@@ -101,16 +101,17 @@ def rel_H(H, Href):
 # what ships and what bench.py times; the others are kept selectable for A/B measurements and must
 # produce the same sums.
 PIPELINES = {
-    "default": dict(variant=2, fuse_finalize=1, nn_mode=0, reuse=1),    # per launch: fused kernel for small scans, search + reduce for large
-    "split": dict(variant=1, fuse_finalize=1, nn_mode=0, reuse=1),      # k_nn_scan + k_reduce_finalize (what large scans run)
+    "default": dict(variant=2, fuse_finalize=1, nn_mode=0, reuse=0),    # per launch: fused kernel for small scans, search + reduce for large
+    "split": dict(variant=1, fuse_finalize=1, nn_mode=0, reuse=0),      # k_nn_scan + k_reduce_finalize (what large scans run)
+    "reuse_auto": dict(variant=1, fuse_finalize=1, nn_mode=0, reuse=1), # ... with certified reuse under its automatic policy (opt-in since round 5)
     "reuse": dict(variant=1, fuse_finalize=1, nn_mode=0, reuse=2),      # ... certified reuse of the previous matches FORCED on every pass it can run on
     "noreuse": dict(variant=1, fuse_finalize=1, nn_mode=0, reuse=0),    # ... and off
-    "mfma": dict(variant=1, fuse_finalize=1, nn_mode=4, reuse=1),       # wave-cooperative search with an MFMA distance filter (k_nn_mfma, round 5)
-    "coop": dict(variant=1, fuse_finalize=1, nn_mode=2, reuse=1),       # wave-cooperative search (k_nn_coop)
-    "nofilter": dict(variant=1, fuse_finalize=1, nn_mode=3, reuse=1),   # centroid searches in float64 throughout (no float32 filter + check)
+    "mfma": dict(variant=1, fuse_finalize=1, nn_mode=4, reuse=0),       # wave-cooperative search with an MFMA distance filter (k_nn_mfma, round 5)
+    "coop": dict(variant=1, fuse_finalize=1, nn_mode=2, reuse=0),       # wave-cooperative search (k_nn_coop)
+    "nofilter": dict(variant=1, fuse_finalize=1, nn_mode=3, reuse=0),   # centroid searches in float64 throughout (no float32 filter + check)
     "unfused": dict(variant=1, fuse_finalize=0, nn_mode=0, reuse=2),    # k_nn_scan + k_reduce + k_finalize
-    "onekernel": dict(variant=0, fuse_finalize=1, nn_mode=0, reuse=1),  # k_linearize_finalize (what small scans run)
-    "onekernel_unfused": dict(variant=0, fuse_finalize=0, nn_mode=0, reuse=1),   # k_linearize + k_finalize
+    "onekernel": dict(variant=0, fuse_finalize=1, nn_mode=0, reuse=0),  # k_linearize_finalize (what small scans run)
+    "onekernel_unfused": dict(variant=0, fuse_finalize=0, nn_mode=0, reuse=0),   # k_linearize + k_finalize
 }
 
 

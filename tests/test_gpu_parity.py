@@ -400,6 +400,7 @@ def test_profile_counters(capi, ctx, g2, pipeline):
     ctx.profile_enable(False)
     want = {"default": dict(nn=0, reduce=0, finalize=0, linearize=5),          # a 2 k-point scan: the fused kernel
             "split": dict(nn=5, reduce=5, finalize=0, linearize=0),
+            "reuse_auto": dict(nn=5, reduce=5, finalize=0, linearize=0),
             "reuse": dict(nn=5, reduce=5, finalize=0, linearize=0, certify=3),     # full, tracking, 3 x certify + list
             "noreuse": dict(nn=5, reduce=5, finalize=0, linearize=0, certify=0),
             "coop": dict(nn=5, reduce=5, finalize=0, linearize=0),
@@ -719,7 +720,7 @@ def test_fuzz_against_oracle(capi, orc, ctx, seed):
     if name in DEV_PIPELINES and not capi.has_dev_kernels():
         # (the developer pipelines run where the developer kernels are: tests/test_gpu_dev_build.py re-runs this test in a
         # process that loaded libpcr_hip_dev.so; the shipped library takes the shipped counterpart)
-        name = {"coop": "split", "unfused": "reuse", "onekernel_unfused": "onekernel"}[name]
+        name = {"coop": "split", "mfma": "split", "unfused": "reuse", "onekernel_unfused": "onekernel"}[name]
     normals = rng.normal(size=target.shape).astype(np.float32)
     normals /= np.linalg.norm(normals, axis=1, keepdims=True)
     o_pts = orc.TargetPoints(target, normals=normals)
