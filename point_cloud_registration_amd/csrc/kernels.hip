@@ -877,6 +877,7 @@ static pcr_status pass_enqueue(Pass *ps) {
             }
             if (ctx->tile_local >= 0) local = ctx->tile_local;
             ps->a.sched_local = local;
+            ps->a.sched_interleave = ctx->tile_interleave;
 #ifdef PCR_DEV
             // (developer build, nn_mode 4: the MFMA-filtered search on every plain full search of a point target)
             const bool mfma = !vox && !ps->q6 && mode == PCR_NN_FULL && ps->t->n > 0 && ctx->nn_mode == 4;

@@ -62,6 +62,9 @@ struct LinArgs {
     uint32_t *nn_j;
     uint32_t *tile_ctr;   // tile counters (64 B apart) of the NN kernels' dynamic hand-out
     int sched_local;      // 1: block-local hand-out (small scans), 0: global counters (see nn_tile_loop)
+    int sched_interleave; // 1: an XCD's tiles are dealt in chunks of PCR_TILE_CHUNK tiles taken round-robin over the whole scan
+                          // instead of one contiguous eighth (round 5: a scan that overlaps the map only partly put all the
+                          // expensive tiles on two or three XCDs)
     // the deeper set of extended lists of a point target (pcr_target::cs_h2 ...; halo2_f = 0: none).  Host-driven passes
     // put the set they chose into gf; the device-resident loop (pose != NULL) picks per iteration (PoseDev::halo_deep)
     const uint32_t *cs_h2;
@@ -464,6 +467,22 @@ __device__ __forceinline__ void linearize_body(const LinArgs &a, const PoseK &P,
 //  * global counters (everything larger): PCR_TILE_CTRS sub-spans, one static round, then device-wide
 //    counters.  With many tiles per wave and costs that differ 10x between regions the static deal
 //    loses more than the atomics cost (1.06 M: 134 vs 147 us; 1e8-point target: 3.3 vs 4.9 ms).
+// Chunk interleave (LinArgs::sched_interleave, round 5).  The schemes below give XCD x the contiguous eighth x of the sorted scan
+// (LOCAL) or eight of 64 contiguous sub-spans (counters): good for the XCD's L2, bad when the COST is not spread like the points --
+// a scan that overlaps the map only partly (bench config plane_b01_crop: 70 % of the points leave the search at once) keeps two or
+// three XCDs busy and five idle (search 200-220 us at every pose where the work is worth ~60).  With the interleave the positions a
+// scheme hands out are read as VIRTUAL: virtual tile v of XCD x is the real tile ((v / CH) * 8 + x) * CH + v % CH, i.e. chunks of
+// CH = 16 tiles (1024 points, still one compact patch) dealt round-robin to the XCDs.
+#ifndef PCR_TILE_CHUNK
+#define PCR_TILE_CHUNK 16
+#endif
+template <int TP>
+__device__ __forceinline__ int64_t nn_tile_real(const LinArgs &a, int xcd, int64_t lo_x, int64_t first) {
+    // `first` is a position inside XCD xcd's virtual range, which starts at lo_x (both multiples of TP)
+    const int64_t v = (first - lo_x) / TP;
+    return (((v / PCR_TILE_CHUNK) * 8 + xcd) * PCR_TILE_CHUNK + v % PCR_TILE_CHUNK) * TP;
+}
+
 template <int LOCAL, int TP, typename Body>
 __device__ __forceinline__ void nn_tile_loop(const LinArgs &a, Body &&body) {
     const int xcd = (int)(blockIdx.x & 7);
@@ -473,6 +492,51 @@ __device__ __forceinline__ void nn_tile_loop(const LinArgs &a, Body &&body) {
     if (LOCAL) {
         if (threadIdx.x == 0) blk_next = 0;
         __syncthreads();
+    }
+    if (a.sched_interleave) {
+        // the XCD's virtual range: whole chunks, enough of them for an eighth of the scan's chunks (rounded up)
+        const int64_t chunk = (int64_t)PCR_TILE_CHUNK * TP;
+        const int64_t nchunks = (a.n + chunk - 1) / chunk;
+        const int64_t vspan = ((nchunks + 7) / 8) * chunk;                     // virtual points per XCD
+        if (LOCAL) {
+            for (;;) {
+                uint32_t k = 0;
+                if (lane == 0) k = atomicAdd(&blk_next, 1u);
+                k = __builtin_amdgcn_readfirstlane(k);
+                const int64_t vfirst = ((int64_t)xb + (int64_t)k * nxb) * TP;
+                if (vfirst >= vspan) break;
+                const int64_t first = nn_tile_real<TP>(a, xcd, 0, vfirst);
+                if (first >= a.n) break;                                       // (real positions grow with the virtual ones)
+                body(first, first + TP < a.n ? first + TP : a.n);
+            }
+        } else {
+            // counters: the XCD's virtual range cut into PCR_TILE_SUB sub-spans, counter (xcd + 8 sub) each; as below, a wave's
+            // first tile of its HOME sub-span is fixed by its index (no atomic), the rest is handed out by the counter
+            const int64_t sspan = (((vspan / TP + PCR_TILE_SUB - 1) / PCR_TILE_SUB)) * TP;
+            const int home = (int)(xb % PCR_TILE_SUB);
+            const uint32_t wrank = (xb / PCR_TILE_SUB) * 4 + (threadIdx.x >> 6);
+            for (int r = 0; r < PCR_TILE_SUB; ++r) {
+                const int sub = (home + r) % PCR_TILE_SUB;
+                const int64_t slo = sspan * sub;
+                const int64_t send = slo + sspan < vspan ? slo + sspan : vspan;
+                const uint32_t nstatic = ((nxb - sub + PCR_TILE_SUB - 1) / PCR_TILE_SUB) * 4;     // home waves of this sub-span
+                bool stat = r == 0;
+                for (;;) {
+                    uint32_t t = 0;
+                    if (stat) { t = wrank; stat = false; }
+                    else {
+                        if (lane == 0) t = atomicAdd(&a.tile_ctr[(xcd + 8 * sub) * PCR_TILE_STRIDE], 1u);
+                        t = __builtin_amdgcn_readfirstlane(t) + nstatic;
+                    }
+                    const int64_t vfirst = slo + (int64_t)t * TP;
+                    if (vfirst >= send) break;
+                    const int64_t first = nn_tile_real<TP>(a, xcd, 0, vfirst);
+                    if (first >= a.n) break;
+                    body(first, first + TP < a.n ? first + TP : a.n);
+                }
+            }
+        }
+        return;
     }
     // global-counter state
     const int64_t gspan = (((a.n + PCR_TILE_CTRS - 1) / PCR_TILE_CTRS) + (TP - 1)) & ~(int64_t)(TP - 1);
