@@ -871,8 +871,13 @@ static pcr_status pass_enqueue(Pass *ps) {
             int local = tiles * 2 <= nb * 4 * 3 ? 1 : 0;
             // (only while a wave gets a handful of tiles: with 38 tiles per wave -- the 12.5 M-point shard -- the static
             // deal loses whatever the pose: plane_100m 2.93 vs 2.82 ms per pass, vplane_10m 1.075 vs 1.06)
+            // Round 5: with the chunk interleave (an XCD's tiles spread over the whole scan) the block-local deal is balanced at the
+            // far poses too and wins at EVERY pose of such scans (1.06 M points, search per trajectory: plane_b01 569 -> 531 us, icp_b01
+            // 2316 -> 2282, resampled 928 -> 874; forced global counters 590 / 2541 / 966) -- but not with tens of tiles per wave
+            // (vplane_10m 3492 -> 5174 us, plane_100m +12 %): profiles/r05_handout_policy.txt
             if (!local && mode != PCR_NN_LIST && tiles <= nb * 4 * 8) {
-                if (a.pose != nullptr) local = mode == PCR_NN_FULL ? 2 : 0;
+                if (ctx->tile_interleave) local = 1;
+                else if (a.pose != nullptr) local = mode == PCR_NN_FULL ? 2 : 0;
                 else if (ps->motion >= 0.0 && ps->motion < ps->f.local_len) local = 1;
             }
             if (ctx->tile_local >= 0) local = ctx->tile_local;

@@ -3,7 +3,7 @@
 root=$(cd "$(dirname "$0")/.." && pwd); out=$root/gpurun_out; export TMPDIR=/tmp; cd /tmp
 for spec in "1.06e6 12" "1e7 6" "1e8 3"; do
   set -- $spec; n=$1; reps=$2
-  tag=r04_set_target_$n
+  tag=${TAG:-r05}_set_target_$n
   python $root/tools/set_target_profile.py $n $reps 2>/dev/null | tail -1 > $out/${tag}_wall.txt; cat $out/${tag}_wall.txt
   for pass in stats fetch write; do
     rm -rf $out/prof_st
