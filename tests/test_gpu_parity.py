@@ -631,6 +631,35 @@ def halo(request, monkeypatch):
     return float(request.param)
 
 
+@pytest.mark.parametrize("name", ["icp", "plane"])
+def test_tile_handout_covers_every_point_once(capi, orc, ctx, name):
+    """The search hands its tiles out in 1024-point chunks dealt round-robin to the XCDs (round 5: nn_tile_loop's chunk
+    interleave; block-local below ~3 M points).  Scan sizes on and around every boundary of that scheme -- one tile, one chunk,
+    one round of eight chunks, partial last tiles and chunks, a size that leaves whole XCDs without work -- must give every
+    point exactly one match: the correspondence count and the sums of the search + reduce pipeline against the oracle and
+    against the one-kernel pipeline, whose loop does not use the hand-out."""
+    from point_cloud_registration_amd.synthetic import street, perturbed_scan
+    kind = {"icp": capi.ICP, "plane": capi.PLANE}[name]
+    okind = {"icp": orc.ICP, "plane": orc.PLANE}[name]
+    target = street(60_000, seed=3)
+    full, _ = perturbed_scan(target, 40_000, seed=4)
+    tgt = capi.Target.points(ctx, target)
+    normals = tgt.estimate_normals(10, compat=True)
+    ot = orc.TargetPoints(target, normals=normals)
+    T = np.eye(4); T[:3, 3] = [0.03, -0.02, 0.05]
+    for n in (1, 63, 64, 65, 1023, 1024, 1025, 2047, 8191, 8192, 8193, 9000, 16383, 16385, 24577, 33000):
+        scan = full[:n]
+        with ctx.pipeline(variant=1, fuse_finalize=1, nn_mode=0, reuse=0):
+            out = capi.linearize(tgt, capi.Scan(ctx, scan), kind, T, 1.0)
+        with ctx.pipeline(variant=0, fuse_finalize=1, nn_mode=0, reuse=0):
+            one = capi.linearize(tgt, capi.Scan(ctx, scan), kind, T, 1.0)
+        H, g, e2, cnt = capi.unpack29(out)
+        Ho, go, e2o, cnto = orc.calc_H_g_e2(okind, ot, T, scan, 1.0, with_count=True)
+        assert cnt == cnto == int(round(one[28])), (name, n, cnt, cnto)
+        assert np.allclose(out, one, rtol=1e-11, atol=1e-9 * max(np.max(np.abs(one)), 1e-30)), (name, n)
+        assert rel_H(H, Ho) < 1e-9 or cnto == 0, (name, n)
+
+
 def test_nn_stress_cell_boundaries(capi, orc, ctx, halo):
     """Exactness where the pruning bounds are tightest (and where the halo lists decide what ring 0 certifies): points and queries ON cell boundaries (lattice
     coordinates that are exact multiples of the cell size), clustered / planar / collinear clouds,
