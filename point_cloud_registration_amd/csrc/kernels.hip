@@ -427,6 +427,11 @@ __device__ __forceinline__ void fix_pending(const LinArgs &a, const PoseK &P, co
 #endif
             nn_point_fix(a, P, ip, a.nn_j[ip] & ~PCR_PENDING_BIT);
         }
+        // (the words rewritten above are read back by OTHER lanes of this wave in reduce_stream -- same-wave global
+        // store -> load ordering holds on gfx950, but say so to the compiler and the memory model explicitly)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         break;
     }
 }
