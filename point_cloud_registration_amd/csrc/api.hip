@@ -199,8 +199,6 @@ extern "C" pcr_status pcr_context_create(int device, pcr_context **out) {
     if (vo && *vo) ctx->vox_occ = atoi(vo) != 0;
     const char *tl = getenv("PCR_TILE_LOCAL");
     if (tl && *tl) ctx->tile_local = atoi(tl) != 0;
-    const char *ti = getenv("PCR_TILE_INTERLEAVE");
-    if (ti && *ti) ctx->tile_interleave = atoi(ti) != 0;
     const char *sd = getenv("PCR_STALL_DEBUG");
     if (sd && *sd) ctx->stall_debug = atoi(sd) != 0;
     const char *rp = getenv("PCR_RETIRE_PERIOD");

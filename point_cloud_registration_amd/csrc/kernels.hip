@@ -881,13 +881,12 @@ static pcr_status pass_enqueue(Pass *ps) {
             // 2316 -> 2282, resampled 928 -> 874; forced global counters 590 / 2541 / 966) -- but not with tens of tiles per wave
             // (vplane_10m 3492 -> 5174 us, plane_100m +12 %): profiles/r05_handout_policy.txt
             if (!local && mode != PCR_NN_LIST && tiles <= nb * 4 * 8) {
-                if (ctx->tile_interleave) local = 1;
+                if (PCR_TILE_INTERLEAVE) local = 1;
                 else if (a.pose != nullptr) local = mode == PCR_NN_FULL ? 2 : 0;
                 else if (ps->motion >= 0.0 && ps->motion < ps->f.local_len) local = 1;
             }
             if (ctx->tile_local >= 0) local = ctx->tile_local;
             ps->a.sched_local = local;
-            ps->a.sched_interleave = ctx->tile_interleave;
 #ifdef PCR_DEV
             // (developer build, nn_mode 4: the MFMA-filtered search on every plain full search of a point target)
             const bool mfma = !vox && !ps->q6 && mode == PCR_NN_FULL && ps->t->n > 0 && ctx->nn_mode == 4;

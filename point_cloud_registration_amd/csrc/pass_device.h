@@ -62,9 +62,6 @@ struct LinArgs {
     uint32_t *nn_j;
     uint32_t *tile_ctr;   // tile counters (64 B apart) of the NN kernels' dynamic hand-out
     int sched_local;      // 1: block-local hand-out (small scans), 0: global counters (see nn_tile_loop)
-    int sched_interleave; // 1: an XCD's tiles are dealt in chunks of PCR_TILE_CHUNK tiles taken round-robin over the whole scan
-                          // instead of one contiguous eighth (round 5: a scan that overlaps the map only partly put all the
-                          // expensive tiles on two or three XCDs)
     // the deeper set of extended lists of a point target (pcr_target::cs_h2 ...; halo2_f = 0: none).  Host-driven passes
     // put the set they chose into gf; the device-resident loop (pose != NULL) picks per iteration (PoseDev::halo_deep)
     const uint32_t *cs_h2;
@@ -467,7 +464,7 @@ __device__ __forceinline__ void linearize_body(const LinArgs &a, const PoseK &P,
 //  * global counters (everything larger): PCR_TILE_CTRS sub-spans, one static round, then device-wide
 //    counters.  With many tiles per wave and costs that differ 10x between regions the static deal
 //    loses more than the atomics cost (1.06 M: 134 vs 147 us; 1e8-point target: 3.3 vs 4.9 ms).
-// Chunk interleave (LinArgs::sched_interleave, round 5).  The schemes below give XCD x the contiguous eighth x of the sorted scan
+// Chunk interleave (round 5; PCR_TILE_INTERLEAVE, compile-time since both schemes in one kernel spill).  The schemes below give XCD x the contiguous eighth x of the sorted scan
 // (LOCAL) or eight of 64 contiguous sub-spans (counters): good for the XCD's L2, bad when the COST is not spread like the points --
 // a scan that overlaps the map only partly (bench config plane_b01_crop: 70 % of the points leave the search at once) keeps two or
 // three XCDs busy and five idle (search 200-220 us at every pose where the work is worth ~60).  With the interleave the positions a
@@ -475,6 +472,9 @@ __device__ __forceinline__ void linearize_body(const LinArgs &a, const PoseK &P,
 // CH = 16 tiles (1024 points, still one compact patch) dealt round-robin to the XCDs.
 #ifndef PCR_TILE_CHUNK
 #define PCR_TILE_CHUNK 16
+#endif
+#ifndef PCR_TILE_INTERLEAVE
+#define PCR_TILE_INTERLEAVE 1
 #endif
 template <int TP>
 __device__ __forceinline__ int64_t nn_tile_real(const LinArgs &a, int xcd, int64_t lo_x, int64_t first) {
@@ -493,7 +493,8 @@ __device__ __forceinline__ void nn_tile_loop(const LinArgs &a, Body &&body) {
         if (threadIdx.x == 0) blk_next = 0;
         __syncthreads();
     }
-    if (a.sched_interleave) {
+#if PCR_TILE_INTERLEAVE
+    {
         // the XCD's virtual range: whole chunks, enough of them for an eighth of the scan's chunks (rounded up)
         const int64_t chunk = (int64_t)PCR_TILE_CHUNK * TP;
         const int64_t nchunks = (a.n + chunk - 1) / chunk;
@@ -536,8 +537,10 @@ __device__ __forceinline__ void nn_tile_loop(const LinArgs &a, Body &&body) {
                 }
             }
         }
-        return;
     }
+#else
+    // (the round-2 to round-4 scheme: one contiguous eighth / eight contiguous 1/64 sub-spans per XCD; kept as a compile-time
+    // variant -- both schemes behind a run-time switch put 784 bytes of k_nn_filter<.., LOCAL = 1>'s state in scratch)
     // global-counter state
     const int64_t gspan = (((a.n + PCR_TILE_CTRS - 1) / PCR_TILE_CTRS) + (TP - 1)) & ~(int64_t)(TP - 1);
     const int home = (int)(xb % PCR_TILE_SUB);
@@ -584,6 +587,7 @@ __device__ __forceinline__ void nn_tile_loop(const LinArgs &a, Body &&body) {
         }
         body(first, end);
     }
+#endif
 }
 
 // One query: scan point i, on its own lane (gathers): the general search.  HALO: the target has the extended

@@ -216,7 +216,6 @@ struct pcr_context {
     int filter_after = 8;        // PCR_FILTER_AFTER: fused small-scan passes a voxel target serves before its filter index is built
     int vox_occ = -1;            // PCR_VOX_OCC (developer): force the centroid search's row-bitmap variant on / off; -1 = by gate / cell ratio
     int tile_local = -1;         // PCR_TILE_LOCAL (developer): force the hand-out policy of k_nn_scan; -1 = automatic
-    int tile_interleave = 1;     // PCR_TILE_INTERLEAVE (default on since round 5): an XCD's tiles in 1024-point chunks dealt round-robin over the scan (nn_tile_loop)
     int reuse = 0;               // 0 off (default since round 5: the automatic policy never engaged on a BASELINE config at tol 1e-3, and the
                                  // state costs 4 bytes per scan point), 1 automatic, 2 forced (track + list whenever the state allows: tests)
     double reuse_tau = 0.0125;   // try it when the scan's typical motion since the last pass is below tau x cell size (a quarter of mu)

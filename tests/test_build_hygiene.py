@@ -54,6 +54,31 @@ def test_ticket_handoff_isa(tmp_path):
     assert found == 6
 
 
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_hot_kernels_use_no_scratch(tmp_path):
+    """Round 5 lesson: a template branch added to k_nn_filter moved 928 bytes of its state per lane to scratch and cost the voxel
+    configs 1.5x, and a run-time switch between two tile hand-out schemes did the same to its block-local variant -- silently, every
+    test green.  The compiler's own resource report is therefore part of the suite: the kernels a plain pass runs (point search,
+    filter search, every reduce kernel, the certificate) use NO scratch; the rare variants (tracking / list passes over voxel
+    targets, the fused small-scan kernels) stay below 128 bytes per lane."""
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
+                        f"-I{REPO}/include", f"-I{CSRC}", "-Rpass-analysis=kernel-resource-usage", "-c",
+                        os.path.join(CSRC, "kernels.hip"), "-o", str(tmp_path / "k.o")], capture_output=True, text=True, check=True)
+    usage, name = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name:
+            usage[name] = int(m.group(1))
+    assert len(usage) > 60, "the resource report was not parsed"
+    hot = [n for n in usage if re.match(r"_Z9k_nn_scanILi0E", n) or "k_nn_filter" in n or "k_reduce_finalize" in n or "k_certify" in n]
+    assert len(hot) >= 30
+    assert {n: usage[n] for n in hot if usage[n] != 0} == {}
+    assert {n: b for n, b in usage.items() if b > 128} == {}
+
+
 @pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not installed")
 def test_oracle_under_sanitizers(tmp_path):
     """the C oracle once under -fsanitize=address,undefined (grid NN, all four
