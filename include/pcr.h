@@ -101,6 +101,15 @@ PCR_API pcr_status pcr_context_trim(pcr_context *ctx, uint64_t *released_bytes);
 PCR_API pcr_status pcr_comm_unique_id(void *id128);
 PCR_API pcr_status pcr_comm_init(pcr_context *ctx, const void *id128, int nranks, int rank);
 PCR_API pcr_status pcr_comm_destroy(pcr_context *ctx);
+/* The same exchange WITHOUT a collective library in the loop (opt-in; RCCL stays the default): every rank exports a block of
+ * slots (pcr_comm_p2p_export -> 64 bytes = a hipIpcMemHandle_t, distributed out of band like the RCCL id), maps its peers'
+ * (pcr_comm_p2p_attach: handles = nranks x 64 bytes in rank order, at most 8 ranks), and a one-wave kernel between fold and
+ * hand-off stores the 29 doubles + a sequence word into every rank's block, waits for everybody's words in its own and sums
+ * the slots in rank order (bit-identical sums on every rank).  Exercised with two processes on one GPU; not yet on xGMI.
+ * pcr_comm_p2p_failed reports whether an exchange gave up waiting for a peer (its sums are NaN then).                   */
+PCR_API pcr_status pcr_comm_p2p_export(pcr_context *ctx, void *handle64);
+PCR_API pcr_status pcr_comm_p2p_attach(pcr_context *ctx, const void *handles, int nranks, int rank);
+PCR_API pcr_status pcr_comm_p2p_failed(pcr_context *ctx, int *failed);
 
 /* ---- targets ------------------------------------------------------------------------
  * pcr_target_points_create replaces ICP.set_target (icp.py:17-22) and the KD-tree half of

@@ -51,6 +51,9 @@ PROTOTYPES = {
     "pcr_comm_unique_id": (C.c_int, [C.c_char_p]),
     "pcr_comm_init": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int]),
     "pcr_comm_destroy": (C.c_int, [_vp]),
+    "pcr_comm_p2p_export": (C.c_int, [_vp, C.c_char_p]),
+    "pcr_comm_p2p_attach": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int]),
+    "pcr_comm_p2p_failed": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "pcr_target_points_create": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_float, C.POINTER(_vp)]),
     "pcr_target_points_create_device": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_float, C.POINTER(_vp)]),
     "pcr_target_set_normals": (C.c_int, [_vp, _f32p]),
@@ -291,6 +294,23 @@ class Context:
         _share_rccl_with_torch()
         check(lib().pcr_comm_init(self.handle, uid, int(nranks), int(rank)))
         self.nranks, self.rank = int(nranks), int(rank)
+
+    def comm_p2p_export(self):
+        """Peer-to-peer transport (include/pcr.h): this rank's 64-byte IPC handle, to be all-gathered out of band."""
+        buf = C.create_string_buffer(64)
+        check(lib().pcr_comm_p2p_export(self.handle, buf))
+        return buf.raw
+
+    def comm_p2p_attach(self, handles, rank):
+        blob = b"".join(handles)
+        assert len(blob) == 64 * len(handles)
+        check(lib().pcr_comm_p2p_attach(self.handle, blob, len(handles), int(rank)))
+        self.nranks, self.rank = len(handles), int(rank)
+
+    def comm_p2p_failed(self):
+        f = C.c_int(0)
+        check(lib().pcr_comm_p2p_failed(self.handle, C.byref(f)))
+        return bool(f.value)
 
     def comm_destroy(self):
         check(lib().pcr_comm_destroy(self.handle))

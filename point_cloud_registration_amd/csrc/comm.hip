@@ -76,15 +76,165 @@ extern "C" pcr_status pcr_comm_init(pcr_context *ctx, const void *id128, int nra
     return PCR_OK;
 }
 
+// ---- peer-to-peer transport (round 5) -------------------------------------------------------------
+// The same 232-byte exchange without a collective library in the loop: every rank owns a block of slots in device memory,
+// exported with hipIpcGetMemHandle and mapped by its peers (one process per GPU).  After the fold a ONE-WAVE kernel stores
+// the rank's 29 doubles into slot (seq mod 64, rank) of EVERY rank's block -- its own included -- drains the stores, then
+// stores the sequence number behind them (system scope: sc0 sc1 payload -> vmcnt(0) -> release flag); it then spins on the
+// nranks sequence words of ITS OWN block (acquire loads, a bounded number of polls) and sums the slots in rank order, so
+// every rank computes bit-identical sums.  Every rank issues the same number of exchanges (the device-resident loop's
+// top-up protocol guarantees it), so a slot is reused only 64 exchanges later, long after everybody read it.
+// Status: exercised with two processes on ONE GPU (tests/test_gpu_two_ranks.py) -- which is also the first time the
+// in-library N > 1 path of pcr_align (exchange between fold and k_gn_update, top-up of the queue) runs with N > 1 at all,
+// RCCL refusing two ranks on one device.  Across xGMI the payload/flag ordering is the textbook one, but it has NOT been run
+// on a multi-GPU node: opt-in (PCR_COMM=p2p), RCCL stays the default.
+#define PCR_P2P_SLOTS 64
+#define PCR_P2P_MAXR 8
+#define PCR_P2P_BYTES ((size_t)PCR_P2P_SLOTS * PCR_P2P_MAXR * 32 * sizeof(double))
+struct P2PState {
+    double *own = nullptr;
+    double *peer[PCR_P2P_MAXR] = {nullptr};
+    bool opened[PCR_P2P_MAXR] = {false};
+    int nranks = 1, rank = 0;
+    unsigned long long seq = 0;
+    int *d_err = nullptr;          // set by a rank that gave up waiting
+    bool finegrained = false;
+};
+struct P2PArgs {
+    double *peer[PCR_P2P_MAXR];
+    int n, rank;
+    unsigned long long seq;
+    double *buf;
+    int *err;
+};
+
+__global__ void __launch_bounds__(64) k_p2p_allreduce(const P2PArgs p) {
+    const int l = threadIdx.x;
+    const size_t slot = (size_t)(p.seq & (PCR_P2P_SLOTS - 1));
+    const size_t mine = (slot * PCR_P2P_MAXR + (size_t)p.rank) * 32;
+    if (l < 29) {
+        const double v = p.buf[l];
+        for (int r = 0; r < p.n; ++r) __hip_atomic_store(&p.peer[r][mine + l], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the payload has left this wave before any flag does
+    __builtin_amdgcn_wave_barrier();
+    if (l < p.n)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(&p.peer[l][mine + 31]), p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    double *own = p.peer[p.rank];
+    bool ok = true;
+    if (l < p.n) {
+        const unsigned long long *flag = reinterpret_cast<const unsigned long long *>(&own[(slot * PCR_P2P_MAXR + (size_t)l) * 32 + 31]);
+        long polls = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != p.seq) {
+            if (++polls > 20000000L) { ok = false; break; }        // ~ seconds: a peer died or never joined
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    if (!__all(ok)) {
+        if (l == 0) __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (l < 29) p.buf[l] = __longlong_as_double(0x7ff8000000000000LL);      // the sums are NOT reduced: poison them
+        return;
+    }
+    __threadfence_system();
+    if (l < 29) {
+        double s = 0.0;
+        for (int r = 0; r < p.n; ++r)
+            s += __hip_atomic_load(&own[(slot * PCR_P2P_MAXR + (size_t)r) * 32 + l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        p.buf[l] = s;
+    }
+}
+
+extern "C" pcr_status pcr_comm_p2p_export(pcr_context *ctx, void *handle64) {
+    PCR_REQUIRE(ctx && handle64, "NULL argument");
+    PCR_REQUIRE(!ctx->comm, "communicator already initialised");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the boundary hands IPC handles around as 64 bytes");
+    HIP_TRY(hipSetDevice(ctx->device));
+    P2PState *st = new P2PState();
+    // fine-grained memory: peers' system-scope stores become visible to this GPU's loads without a kernel boundary
+    hipError_t e = hipExtMallocWithFlags((void **)&st->own, PCR_P2P_BYTES, hipDeviceMallocFinegrained);
+    st->finegrained = e == hipSuccess;
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc((void **)&st->own, PCR_P2P_BYTES); }
+    if (e != hipSuccess) { delete st; pcr_set_error("p2p slots: %s", hipGetErrorString(e)); return PCR_ERR_HIP; }
+    hipIpcMemHandle_t h;
+    e = hipIpcGetMemHandle(&h, st->own);
+    if (e != hipSuccess && st->finegrained) {                    // (some runtimes export coarse-grained blocks only)
+        (void)hipGetLastError(); (void)hipFree(st->own); st->own = nullptr; st->finegrained = false;
+        e = hipMalloc((void **)&st->own, PCR_P2P_BYTES);
+        if (e == hipSuccess) e = hipIpcGetMemHandle(&h, st->own);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (st->own) (void)hipFree(st->own);
+        delete st;
+        pcr_set_error("hipIpcGetMemHandle: %s", hipGetErrorString(e));
+        return PCR_ERR_COMM;
+    }
+    HIP_TRY(hipMemset(st->own, 0, PCR_P2P_BYTES));
+    HIP_TRY(hipMalloc((void **)&st->d_err, sizeof(int)));
+    HIP_TRY(hipMemset(st->d_err, 0, sizeof(int)));
+    memcpy(handle64, &h, 64);
+    ctx->comm = st; ctx->comm_kind = 1; ctx->nranks = 1; ctx->rank = 0;
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_comm_p2p_attach(pcr_context *ctx, const void *handles, int nranks, int rank) {
+    PCR_REQUIRE(ctx && handles, "NULL argument");
+    PCR_REQUIRE(ctx->comm && ctx->comm_kind == 1, "pcr_comm_p2p_export first");
+    PCR_REQUIRE(nranks >= 1 && nranks <= PCR_P2P_MAXR && rank >= 0 && rank < nranks, "bad rank / nranks (at most 8 ranks)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    P2PState *st = (P2PState *)ctx->comm;
+    for (int r = 0; r < nranks; ++r) {
+        if (r == rank) { st->peer[r] = st->own; continue; }
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char *)handles + 64 * (size_t)r, 64);
+        void *p = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) { (void)hipGetLastError(); pcr_set_error("hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e)); return PCR_ERR_COMM; }
+        st->peer[r] = (double *)p; st->opened[r] = true;
+    }
+    st->nranks = nranks; st->rank = rank;
+    ctx->nranks = nranks; ctx->rank = rank;
+    return PCR_OK;
+}
+
 extern "C" pcr_status pcr_comm_destroy(pcr_context *ctx) {
     if (!ctx || !ctx->comm) return PCR_OK;
     (void)hipStreamSynchronize(ctx->stream);
-    if (g_nccl.CommDestroy) (void)g_nccl.CommDestroy((nccl_comm_t)ctx->comm);
-    ctx->comm = nullptr; ctx->nranks = 1; ctx->rank = 0;
+    if (ctx->comm_kind == 1) {
+        P2PState *st = (P2PState *)ctx->comm;
+        for (int r = 0; r < PCR_P2P_MAXR; ++r) if (st->opened[r]) (void)hipIpcCloseMemHandle(st->peer[r]);
+        if (st->own) (void)hipFree(st->own);
+        if (st->d_err) (void)hipFree(st->d_err);
+        delete st;
+    } else if (g_nccl.CommDestroy) {
+        (void)g_nccl.CommDestroy((nccl_comm_t)ctx->comm);
+    }
+    ctx->comm = nullptr; ctx->comm_kind = 0; ctx->nranks = 1; ctx->rank = 0;
+    return PCR_OK;
+}
+
+// 1 when a peer-to-peer exchange of this context gave up waiting for a peer (its sums were poisoned with NaN)
+extern "C" pcr_status pcr_comm_p2p_failed(pcr_context *ctx, int *failed) {
+    PCR_REQUIRE(ctx && failed, "NULL argument");
+    *failed = 0;
+    if (!ctx->comm || ctx->comm_kind != 1) return PCR_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(failed, ((P2PState *)ctx->comm)->d_err, sizeof(int), hipMemcpyDeviceToHost));
     return PCR_OK;
 }
 
 pcr_status pcr_comm_allreduce29(pcr_context *ctx, double *d_buf) {
+    if (ctx->comm_kind == 1) {
+        P2PState *st = (P2PState *)ctx->comm;
+        P2PArgs a;
+        for (int r = 0; r < PCR_P2P_MAXR; ++r) a.peer[r] = st->peer[r];
+        a.n = st->nranks; a.rank = st->rank; a.seq = ++st->seq; a.buf = d_buf; a.err = st->d_err;
+        hipLaunchKernelGGL(k_p2p_allreduce, dim3(1), dim3(64), 0, ctx->stream, a);
+        HIP_TRY(hipGetLastError());
+        return PCR_OK;
+    }
     // ncclFloat64 = 8, ncclSum = 0 (rccl.h); in place, on the stream the kernels ran on
     NCCL_TRY(g_nccl.AllReduce(d_buf, d_buf, 29, 8, 0, (nccl_comm_t)ctx->comm, ctx->stream));
     return PCR_OK;

@@ -235,7 +235,8 @@ struct pcr_context {
     int64_t prof_launches[PCR_K_COUNT] = {0};
     double prof_ms[PCR_K_COUNT] = {0};
     // RCCL
-    void *comm = nullptr;
+    void *comm = nullptr;        // ncclComm_t (comm_kind 0) or the peer-to-peer state (comm_kind 1, comm.hip: P2PState)
+    int comm_kind = 0;
     int nranks = 1, rank = 0;
     // cache of free device blocks (temporaries of the build paths): (capacity, pointer), total bytes.
     // cache / cache_bytes / owned are guarded by cache_mu: a Scan / Target finalizer on one host thread (ctypes drops the

@@ -38,4 +38,4 @@ timeout 400 python tools/soak.py 150 > $o/${TAG}_soak.txt 2>&1; tail -3 $o/${TAG
 TAG=$TAG tools/collect_set_target_profiles.sh > $o/${TAG}_set_target.log 2>&1; tail -4 $o/${TAG}_set_target.log
 # (the million-pass rare-event trace of rounds 3-4 is not repeated: root-caused, docs/EXPERIMENTS.md)
 # parity margins against the reference-run fixtures (worst max|dH|/max|H| per class and scan), for profiles/<tag>_g8_parity.txt
-timeout 900 python -m pytest tests/test_gpu_fullsize.py -m gpu -q -s -k "g8_hip or g10_hip" 2>&1 | grep -E "^g8|^g10|passed|failed" > $o/${TAG}_g8_parity.txt; cat $o/${TAG}_g8_parity.txt
+timeout 900 python -m pytest tests/test_gpu_fullsize.py -m gpu -q -s -k "g8_hip or g10_hip" 2>&1 | grep -oE "g8 [a-z0-9]+: worst.*|g10 [a-z]+: worst.*|[0-9]+ passed.*|[0-9]+ failed.*" > $o/${TAG}_g8_parity.txt; cat $o/${TAG}_g8_parity.txt
