@@ -477,7 +477,8 @@ def main():
                        "max_dist": max_dist, "voxel_size": voxel_size, "parallelism": f"scan-shard x{world}",
                        "backend": (args.backend if use_comm else None),
                        "allreduce_transport": (None if comm is None else
-                                               ("rccl-in-stream" if comm.in_library else f"host-{args.backend}")),
+                                               (("p2p-ipc-in-stream" if comm.transport == "p2p" else "rccl-in-stream")
+                                                if comm.in_library else f"host-{args.backend}")),
                        "devices_visible": torch.cuda.device_count(),
                        "scan_points_job": int(n_scan_job),
                        "nn_index": {"cell": info["cell"], "dims": info["dims"], "occupied_cells": info["occupied"],
@@ -507,7 +508,9 @@ def main():
         if per_rank is not None:
             line["per_rank_kernel_ms"] = per_rank
         if world == 1 and not use_comm and not os.environ.get("PCR_BENCH_NO_RCCL_PROBE") and not args.pmc_child:
-            line["rccl_1rank"] = rccl_one_rank_probe(ctx, step, args.steps, sync_all)
+            one = rccl_one_rank_probe(ctx, step, args.steps, sync_all)
+            line["rccl_1rank"] = one.get("rccl", one)                 # in-stream exchange with ONE rank attached: everything but the hops
+            line["p2p_1rank"] = one.get("p2p", one)                   # ... and the same for the peer-to-peer transport (PCR_COMM=p2p)
         if world == 1 and not args.pmc_child:
             line["seam"] = seam_timings(kind_name, target, scan, tgt, sc, kind, traj, max_dist, voxel_size, n_target)
         if world == 1 and not args.no_cpu_baseline:
@@ -535,31 +538,37 @@ def rccl_one_rank_probe(ctx, step, steps, sync_all):
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(port))
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
             pdist.init_from_env("nccl")
-        comm = pdist.Communicator(ctx, in_library=True)
+        res = {}
         try:
-            if not comm.in_library:
-                return {"error": "RCCL communicator not available inside libpcr_hip.so"}
-            for k in range(5):
-                step(k)
-            ctx.profile_enable(True, period=1); ctx.profile_reset()
-            sync_all()
-            t0 = time.perf_counter()
-            for k in range(steps):
-                step(k)
-            sync_all()
-            dt = time.perf_counter() - t0
-            prof = ctx.profile_read(); ctx.profile_enable(False)
-            sync_all()
-            t0 = time.perf_counter()
-            for k in range(steps):
-                step(k)
-            sync_all()
-            dt_off = time.perf_counter() - t0
-            n, ms = prof["allreduce"]
-            return {"ms_per_step_events_off": round(dt_off / steps * 1e3, 4), "ms_per_step_profiled": round(dt / steps * 1e3, 4),
-                    "allreduce29_plus_publish_avg_ms": round(ms / max(n, 1), 5), "launches": n}
+            for transport in ("rccl", "p2p"):
+                comm = pdist.Communicator(ctx, in_library=True, transport=transport)
+                try:
+                    if not comm.in_library:
+                        res[transport] = {"error": f"{transport} communicator not available inside libpcr_hip.so"}
+                        continue
+                    for k in range(5):
+                        step(k)
+                    ctx.profile_enable(True, period=1); ctx.profile_reset()
+                    sync_all()
+                    t0 = time.perf_counter()
+                    for k in range(steps):
+                        step(k)
+                    sync_all()
+                    dt = time.perf_counter() - t0
+                    prof = ctx.profile_read(); ctx.profile_enable(False)
+                    sync_all()
+                    t0 = time.perf_counter()
+                    for k in range(steps):
+                        step(k)
+                    sync_all()
+                    dt_off = time.perf_counter() - t0
+                    n, ms = prof["allreduce"]
+                    res[transport] = {"ms_per_step_events_off": round(dt_off / steps * 1e3, 4), "ms_per_step_profiled": round(dt / steps * 1e3, 4),
+                                      "allreduce29_plus_publish_avg_ms": round(ms / max(n, 1), 5), "launches": n}
+                finally:
+                    comm.close()
+            return res
         finally:
-            comm.close()
             torch.distributed.destroy_process_group()
     except Exception as e:                                   # noqa: BLE001 -- a probe must not take the bench line down
         return {"error": f"{type(e).__name__}: {e}"[:300]}

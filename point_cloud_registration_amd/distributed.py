@@ -27,7 +27,10 @@ def shard_scan(source, rank, world):
 
 
 class Communicator:
-    def __init__(self, ctx=None, in_library=True, group=None):
+    """``transport`` (in-library exchanges only): "rccl" (default) or "p2p" -- the peer-to-peer exchange of csrc/comm.hip
+    (IPC-mapped slots, no collective library in the loop; ``PCR_COMM=p2p`` selects it where no argument is given)."""
+
+    def __init__(self, ctx=None, in_library=True, group=None, transport=None):
         import torch.distributed as dist
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised (torchrun / init_process_group)")
@@ -37,7 +40,32 @@ class Communicator:
         self.world = dist.get_world_size(group)
         self.ctx = ctx
         self.in_library = bool(in_library) and ctx is not None
-        if self.in_library:
+        self.transport = (transport or os.environ.get("PCR_COMM") or "rccl").lower() if self.in_library else "host"
+        if self.in_library and self.transport == "p2p":
+            ok, handle = 1, None
+            try:
+                handle = ctx.comm_p2p_export()
+            except Exception as exc:
+                ok = 0
+                print(f"[pcr] rank {self.rank}: peer-to-peer export failed ({exc})", flush=True)
+            handles = [None] * self.world
+            dist.all_gather_object(handles, handle, group=group)
+            if ok and all(h is not None for h in handles):
+                try:
+                    ctx.comm_p2p_attach(handles, self.rank)
+                except Exception as exc:
+                    ok = 0
+                    print(f"[pcr] rank {self.rank}: peer-to-peer attach failed ({exc})", flush=True)
+            else:
+                ok = 0
+            flags = [None] * self.world
+            dist.all_gather_object(flags, ok, group=group)
+            if min(flags) == 0:                              # every rank takes the same path
+                ctx.comm_destroy()
+                self.in_library = False
+                self.transport = "host"
+            dist.barrier(group=group)                        # nobody exchanges before everybody has mapped everybody
+        elif self.in_library:
             from . import _capi
             ok = 1
             try:
@@ -61,6 +89,7 @@ class Communicator:
                 if ok:
                     ctx.comm_destroy()
                 self.in_library = False
+                self.transport = "host"
 
     def allreduce(self, out29):
         """Host-side sum of the 29 doubles over all ranks (gloo path)."""

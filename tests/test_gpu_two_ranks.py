@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, transport=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0", PCR_DEVICE="0")
     sys.path.insert(0, REPO)
@@ -32,7 +32,8 @@ def _worker(rank, world, port, q):
     pdist.init_from_env("gloo")
     g2 = load_golden("g2_mini_street.npz")
     ctx = _capi.get_context(0)
-    comm = pdist.Communicator(ctx, in_library=True)          # RCCL init fails (same GPU twice) -> agreed fallback
+    # RCCL init fails (same GPU twice) -> agreed fallback; the peer-to-peer transport does work between two processes on one GPU
+    comm = pdist.Communicator(ctx, in_library=True, transport=transport)
     md, vs = float(g2["max_dist"]), float(g2["voxel_size"])
     shard = pdist.shard_scan(g2["source"], rank, world)
     out = {}
@@ -50,27 +51,42 @@ def _worker(rank, world, port, q):
         T = reg.align(shard, np.eye(4))
         H, g, e2 = reg.calc_H_g_e2(g2["T"], shard)
         out[name] = (T, H, reg.last_iterations, reg.last_correspondences)
-    q.put((rank, comm.in_library, out))
+    failed = ctx.comm_p2p_failed() if (comm.in_library and comm.transport == "p2p") else False
+    q.put((rank, comm.in_library, out, comm.transport, failed))
     dist.barrier()
     comm.close()
     dist.destroy_process_group()
 
 
-def test_two_ranks_one_gpu_sharded_plane_icp(g2):
+@pytest.mark.parametrize("transport", ["rccl", "p2p"])
+def test_two_ranks_one_gpu_sharded_plane_icp(g2, transport):
+    """transport "p2p" (round 5): the in-library exchange between two PROCESSES on the one GPU -- IPC-mapped slots, a one-wave
+    kernel between fold and hand-off -- which is also the first time the N > 1 branch of the device-resident loop (exchange in
+    front of k_gn_update, the top-up of the queue) runs with more than one rank."""
     import multiprocessing as mp            # (not torch.multiprocessing: keep torch out of the parent)
+    import queue as queue_mod
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, transport)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    try:
+        res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    except queue_mod.Empty:
+        for p in procs:
+            p.kill()
+        pytest.fail("a rank did not report within 600 s")
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    (_, lib_a, out_a), (_, lib_b, out_b) = res
-    assert lib_a == lib_b                                     # both ranks took the same transport
-    print("transport:", "RCCL inside libpcr_hip.so" if lib_a else "host all-reduce (gloo) fallback")
+    (_, lib_a, out_a, tr_a, fail_a), (_, lib_b, out_b, tr_b, fail_b) = res
+    assert lib_a == lib_b and tr_a == tr_b                    # both ranks took the same transport
+    print("transport:", tr_a, "inside libpcr_hip.so" if lib_a else "(host all-reduce, gloo: the agreed fallback)")
+    if transport == "p2p":
+        if not lib_a:
+            pytest.skip("hipIpc between two processes is not available on this box: the ranks agreed on the host fallback")
+        assert not fail_a and not fail_b
     for name in ("plane", "icp", "vplane", "ndt"):
         (Ta, Ha, ita, ca), (Tb, Hb, itb, cb) = out_a[name], out_b[name]
         assert np.array_equal(Ta, Tb) and np.array_equal(Ha, Hb) and ita == itb and ca == cb, name
