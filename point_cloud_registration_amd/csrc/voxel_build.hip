@@ -187,8 +187,7 @@ static pcr_status voxel_build(pcr_context *ctx, const T *d_xyz, int64_t n, doubl
             hipLaunchKernelGGL(k_voxel_stats<T>, dim3((unsigned)((nu + 3) / 4)), dim3(256), 0, ctx->stream, d_xyz, i2.p,
                                ukeys.p, counts.p, seg.p, flags.p, nu, min_points, key_bias, t->st_mean, t->st_cov, t->st_norm, t->st_icov,
                                t->st_counts, t->st_keys);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(hipGetLastError());          // (no synchronisation: the centroid grid is built on the same stream)
         }
         t->n = nk;
     }
