@@ -161,7 +161,9 @@ def live_traffic(args):
         out = tempfile.mkdtemp(prefix="pcr_pmc_", dir="/tmp")
         try:
             r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "rocpd", "-d", out, "-o", "r", "--"] + child,
-                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+                               cwd="/tmp", env=env, capture_output=True, text=True,
+                               timeout=float(os.environ.get("PCR_BENCH_PMC_TIMEOUT", "240")))   # (a pass takes 10-60 s; on a timeout
+            # the line says so in roofline.traffic_source.live_attempt and falls back to profiles/pmc_summary.json)
             dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
             if r.returncode != 0 or not dbs:
                 errs.append(f"{counter}: rc {r.returncode} {r.stderr[-200:]}")

@@ -238,17 +238,42 @@ __global__ void __launch_bounds__(256) k_gap_copy(const uint32_t *__restrict__ c
 // the 251 M cells of the 1e8-point target).  Every pass carries the cell the minimum came from; its
 // first point becomes the seed of the empty cell.
 #define GAP_INF 255
+// x pass.  A block first turns the occupancy of its 256 cells (+ 64 on either side) into bits in LDS; a cell then finds the
+// nearest occupied cell of its row with two bit scans over a 31-bit window instead of up to 62 reads of cell_start (round 5:
+// 46 us -> per 3 M cells; an empty cell far from any point, the common case in a street scene, used to run the full loop).
+static_assert(PCR_GAP_MAX <= 31, "the window of k_gap_x is one 64-bit word");
 __global__ void __launch_bounds__(256) k_gap_x(const uint32_t *__restrict__ cs, int nx, int64_t ncells, uint8_t *gap,
                                                uint32_t *src) {
-    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    __shared__ unsigned long long occ[6];                 // bit b of word w: cell c0 - 64 + 64 w + b
+    const int64_t c0 = (int64_t)blockIdx.x * 256;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    auto occupied = [&](int64_t cc) { return cc >= 0 && cc < ncells && cs[cc + 1] != cs[cc]; };
+    const unsigned long long m = __ballot(occupied(c0 + t));
+    if (lane == 0) occ[1 + wave] = m;
+    if (wave < 2) {
+        const unsigned long long m2 = __ballot(occupied(wave == 0 ? c0 - 64 + lane : c0 + 256 + lane));
+        if (lane == 0) occ[wave == 0 ? 0 : 5] = m2;
+    }
+    __syncthreads();
+    const int64_t c = c0 + t;
     if (c >= ncells) return;
     const int x = (int)(c % nx);
+    const int W = PCR_GAP_MAX;
+    const int lo = 64 + t - W, wi = lo >> 6, sh = lo & 63;          // window bit i = cell c - W + i
+    unsigned long long win = occ[wi] >> sh;
+    if (sh) win |= occ[wi + 1] << (64 - sh);
+    win &= (1ull << (2 * W + 1)) - 1ull;
+    const int dl_max = min(x, W), dr_max = min(nx - 1 - x, W);       // stay inside the row
+    win &= ~((1ull << (W - dl_max)) - 1ull);
+    win &= (1ull << (W + dr_max + 1)) - 1ull;
+    const unsigned left = (unsigned)(win & ((1ull << (W + 1)) - 1ull));     // bit W - d: the cell d to the left (d = 0: itself)
+    const unsigned right = (unsigned)(win >> W);                            // bit d: the cell d to the right
+    const int dl = left ? W - (31 - __clz((int)left)) : GAP_INF;
+    const int dr = right ? __ffs((int)right) - 1 : GAP_INF;
     uint8_t g = GAP_INF;
     uint32_t from = 0xffffffffu;
-    for (int d = 0; d <= PCR_GAP_MAX; ++d) {
-        if (x - d >= 0 && cs[c - d + 1] != cs[c - d]) { g = (uint8_t)d; from = (uint32_t)(c - d); break; }
-        if (x + d < nx && cs[c + d + 1] != cs[c + d]) { g = (uint8_t)d; from = (uint32_t)(c + d); break; }
-    }
+    if (dl <= dr && dl != GAP_INF) { g = (uint8_t)dl; from = (uint32_t)(c - dl); }      // (equal distances: the left cell, as the loop had it)
+    else if (dr != GAP_INF) { g = (uint8_t)dr; from = (uint32_t)(c + dr); }
     gap[c] = g; src[c] = from;
 }
 
