@@ -430,14 +430,21 @@ extern "C" pcr_status pcr_profile_read(pcr_context *ctx, int64_t launches[PCR_K_
 }
 
 // ---- small helpers ---------------------------------------------------------------------------
+// sync = false: the caller's next step synchronises the stream before the entry point returns (the build that consumes the
+// array does); a wait here only parks the device for the host's wake-up (35-45 us per set_target / scan set-up, round 5).  Such
+// a caller passes its status through `synced`, which waits on the error paths that return before that step.
 template <typename T>
-static pcr_status upload(pcr_context *ctx, const T *host, size_t count, DevBuf<T> *buf, bool exact = false) {
+static pcr_status upload(pcr_context *ctx, const T *host, size_t count, DevBuf<T> *buf, bool exact = false, bool sync = true) {
     HIP_TRY(exact ? buf->alloc_exact(count) : buf->alloc(count));
     if (count) {
         HIP_TRY(hipMemcpyAsync(buf->p, host, sizeof(T) * count, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (sync) HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     return PCR_OK;
+}
+static pcr_status synced(pcr_context *ctx, pcr_status s) {
+    if (s != PCR_OK) (void)hipStreamSynchronize(ctx->stream);      // (the host array may still be being read)
+    return s;
 }
 
 void pcr_target_release(pcr_target *t);
@@ -476,9 +483,9 @@ extern "C" pcr_status pcr_target_points_create(pcr_context *ctx, const float *xy
     HIP_TRY(hipSetDevice(ctx->device));
     CtxScope scope(ctx);
     DevBuf<float> d_xyz, d_nrm;
-    PCR_TRY(upload<float>(ctx, xyz, (size_t)n * 3, &d_xyz));
-    if (normals_or_null) PCR_TRY(upload<float>(ctx, normals_or_null, (size_t)n * 3, &d_nrm));
-    return points_create_common(ctx, d_xyz.p, n, d_nrm.p, cell_hint, out);
+    PCR_TRY(upload<float>(ctx, xyz, (size_t)n * 3, &d_xyz, false, false));
+    if (normals_or_null) PCR_TRY(synced(ctx, upload<float>(ctx, normals_or_null, (size_t)n * 3, &d_nrm, false, false)));
+    return synced(ctx, points_create_common(ctx, d_xyz.p, n, d_nrm.p, cell_hint, out));
 }
 
 extern "C" pcr_status pcr_target_points_create_device(pcr_context *ctx, const float *d_xyz, int64_t n,
@@ -675,8 +682,8 @@ extern "C" pcr_status pcr_scan_create(pcr_context *ctx, const float *xyz, int64_
     HIP_TRY(hipSetDevice(ctx->device));
     CtxScope scope(ctx);
     DevBuf<float> d_xyz;
-    PCR_TRY(upload<float>(ctx, xyz, (size_t)n * 3, &d_xyz));
-    return pcr_scan_create_device(ctx, d_xyz.p, n, flags, out);
+    PCR_TRY(upload<float>(ctx, xyz, (size_t)n * 3, &d_xyz, false, false));
+    return synced(ctx, pcr_scan_create_device(ctx, d_xyz.p, n, flags, out));
 }
 
 extern "C" pcr_status pcr_scan_size(pcr_scan *s, int64_t *n) {

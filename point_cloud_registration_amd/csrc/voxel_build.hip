@@ -205,13 +205,14 @@ extern "C" pcr_status pcr_target_voxels_create(pcr_context *ctx, const void *xyz
     const size_t elem = xyz_is_f64 ? 8 : 4;
     DevBuf<char> d_xyz;
     HIP_TRY(d_xyz.alloc_bytes(elem * 3 * (size_t)(n > 0 ? n : 1)));
-    if (n > 0) {
-        HIP_TRY(hipMemcpyAsync(d_xyz.p, xyz, elem * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-    }
+    if (n > 0) HIP_TRY(hipMemcpyAsync(d_xyz.p, xyz, elem * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     int64_t nonfinite = 0;
     float lo[3], hi[3];
-    PCR_TRY(pcr_count_nonfinite(ctx, d_xyz.p, xyz_is_f64, n, &nonfinite, lo, hi));
+    // (no wait behind the copy: the bounding box's read-back synchronises the stream, on every path out of it)
+    {
+        const pcr_status sb = pcr_count_nonfinite(ctx, d_xyz.p, xyz_is_f64, n, &nonfinite, lo, hi);
+        if (sb != PCR_OK) { (void)hipStreamSynchronize(ctx->stream); return sb; }
+    }
     if (nonfinite > 0) {               // floor(NaN / voxel_size).astype(int64) is undefined in the reference as well
         pcr_set_error("cloud has %lld point(s) with a non-finite coordinate; drop them first", (long long)nonfinite);
         return PCR_ERR_INVALID;

@@ -903,6 +903,43 @@ def test_fuzz_knn(capi, orc, ctx, seed):
     assert np.array_equal(i, io)
 
 
+@pytest.mark.parametrize("case", ["lattice", "dense_spot", "duplicates", "sheet", "two_scales"])
+@pytest.mark.parametrize("k", [1, 15, 16, 17])
+def test_knn_constructed_cases(capi, orc, ctx, case, k):
+    """The k <= 16 search's branches on clouds built to take them (knn_normals.hip: knn_collect): exact ties by the
+    hundred (a lattice: order by original index), more points than the queue holds inside the first distance class
+    (a dense spot: handed to the list search), repeated points (distance 0 several times), a flat sheet, a cloud
+    with two densities (sparse part: no bound from the 27-cell block), queries outside the grid -- and the same
+    clouds through the k > 16 list.  Distances and indices bit-exact against brute force."""
+    rng = np.random.default_rng(7)
+    if case == "lattice":
+        a = np.arange(12, dtype=np.float32) * np.float32(0.25)
+        pts = np.stack(np.meshgrid(a, a, a, indexing="ij"), -1).reshape(-1, 3)
+        pts = pts[rng.permutation(len(pts))]
+    elif case == "dense_spot":
+        pts = np.vstack([rng.normal(0, 0.004, (5000, 3)) + [1.0, 2.0, 0.5], rng.uniform(-5, 5, (2500, 3))]).astype(np.float32)
+    elif case == "duplicates":
+        base = rng.uniform(-2, 2, (1500, 3)).astype(np.float32)
+        pts = np.vstack([base, base, base[:700]])[rng.permutation(3700)]
+    elif case == "sheet":
+        pts = np.hstack([rng.uniform(-4, 4, (6000, 2)), np.zeros((6000, 1))]).astype(np.float32)
+    else:
+        pts = np.vstack([rng.uniform(-1, 1, (6000, 3)), rng.uniform(-40, 40, (1500, 3))]).astype(np.float32)
+    q = np.vstack([pts[rng.integers(0, len(pts), 300)],
+                   (pts[rng.integers(0, len(pts), 150)].astype(np.float64) + rng.normal(0, 0.1, (150, 3))).astype(np.float32),
+                   (rng.uniform(-1, 1, (50, 3)) * 300).astype(np.float32)])
+    t = capi.Target.points(ctx, pts)
+    d, i = t.knn_query(q, k)
+    do, io = orc.knn_brute(pts, q, k)
+    assert np.array_equal(d, do)
+    assert np.array_equal(i, io)
+    if k in (15, 17):
+        n_gpu = t.estimate_normals(k, compat=True)
+        _, ip = orc.knn_brute(pts, pts, k)
+        rows = np.arange(0, len(pts), max(len(pts) // 150, 1))
+        _assert_smallest_eigvec(pts, ip, n_gpu, rows, f"{case} k={k}")
+
+
 # ----------------------------------------------------------------------------- certified reuse
 def _small_steps(rng, T0, n, rot, trans):
     """A pose sequence the way a converging Gauss-Newton loop produces one: steps that shrink."""
