@@ -8,9 +8,11 @@
 // Sorting and prefix sums use rocPRIM through hipCUB (device-wide radix sort / scan); the
 // kernels around them are hand-written.  Everything runs on the context's stream.
 #include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 #include <math.h>
 #include <cmath>
+#include <vector>
 
 #include "nn_device.h"
 #include "gn_math.h"
@@ -30,6 +32,9 @@ static inline float ord2f(unsigned u) {
 // box[0..2] = min (ordered-uint encoding), box[3..5] = max over the FINITE points; box[6] = number of
 // points with a NaN / inf coordinate (they are left out of the box: an inf would blow the grid up, a
 // NaN is invisible to fmin/fmax anyway)
+#define BBOX_SLOTS 64
+#define BBOX_STRIDE 32                  // words: a slot per 128-byte line; line 0 holds the folded box
+#define BBOX_WORDS (BBOX_STRIDE * (1 + BBOX_SLOTS))
 template <typename T>
 __global__ void __launch_bounds__(256) k_bbox(const T *__restrict__ xyz, int64_t n, unsigned *box) {
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -66,25 +71,47 @@ __global__ void __launch_bounds__(256) k_bbox(const T *__restrict__ xyz, int64_t
         sbad[wave] = bad;
     }
     __syncthreads();
+    // (1024 blocks x 7 atomics on one cache line serialise in its L2 channel -- most of this kernel's 29 us at 1.06 M points:
+    // the blocks spread over BBOX_SLOTS lines, k_bbox_final folds them into box[0..6])
+    unsigned *slot = box + BBOX_STRIDE * (1 + blockIdx.x % BBOX_SLOTS);
     if (threadIdx.x < 3) {
         const int a = threadIdx.x;
         const float l = fminf(fminf(slo[0][a], slo[1][a]), fminf(slo[2][a], slo[3][a]));
         const float h = fmaxf(fmaxf(shi[0][a], shi[1][a]), fmaxf(shi[2][a], shi[3][a]));
-        atomicMin(&box[a], f2ord(l));
-        atomicMax(&box[3 + a], f2ord(h));
+        atomicMin(&slot[a], f2ord(l));
+        atomicMax(&slot[3 + a], f2ord(h));
     }
     if (threadIdx.x == 3) {
         const unsigned b = sbad[0] + sbad[1] + sbad[2] + sbad[3];
-        if (b) atomicAdd(&box[6], b);
+        if (b) atomicAdd(&slot[6], b);
     }
 }
 
 // lo / hi over the finite points (0 when there is none); *nonfinite = how many points were left out
-__global__ void __launch_bounds__(64) k_bbox_init(unsigned *box) {
-    if (threadIdx.x < 7) box[threadIdx.x] = threadIdx.x < 3 ? 0xffffffffu : 0u;
+__global__ void __launch_bounds__(64) k_bbox_init(unsigned *box) {           // one lane per slot
+    unsigned *slot = box + BBOX_STRIDE * (1 + threadIdx.x);
+#pragma unroll
+    for (int a = 0; a < 7; ++a) slot[a] = a < 3 ? 0xffffffffu : 0u;
 }
+__global__ void __launch_bounds__(64) k_bbox_final(unsigned *box) {
+    const unsigned *slot = box + BBOX_STRIDE * (1 + threadIdx.x);
+    unsigned v[7];
+#pragma unroll
+    for (int a = 0; a < 7; ++a) v[a] = slot[a];
+#pragma unroll
+    for (int a = 0; a < 7; ++a)
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned o = __shfl_xor(v[a], off, 64);
+            v[a] = a < 3 ? min(v[a], o) : (a < 6 ? max(v[a], o) : v[a] + o);
+        }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int a = 0; a < 7; ++a) box[a] = v[a];
+    }
+}
+static_assert(BBOX_SLOTS == 64, "k_bbox_init / k_bbox_final: one lane per slot");
 
-// the box of k_bbox, launched only (box: 7 words on the device)
+// the box of k_bbox, launched only (box: BBOX_WORDS words on the device, the result in the first 7)
 template <typename T>
 static pcr_status device_bbox_launch(pcr_context *ctx, const T *d_xyz, int64_t n, unsigned *d_box) {
     hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(64), 0, ctx->stream, d_box);
@@ -93,6 +120,7 @@ static pcr_status device_bbox_launch(pcr_context *ctx, const T *d_xyz, int64_t n
         if (nb > 1024) nb = 1024;
         hipLaunchKernelGGL(k_bbox<T>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_xyz, n, d_box);
     }
+    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(64), 0, ctx->stream, d_box);
     HIP_TRY(hipGetLastError());
     return PCR_OK;
 }
@@ -109,7 +137,7 @@ template <typename T>
 static pcr_status device_bbox(pcr_context *ctx, const T *d_xyz, int64_t n, float lo[3], float hi[3],
                               int64_t *nonfinite = nullptr) {
     DevBuf<unsigned> d_box;
-    HIP_TRY(d_box.alloc(7));
+    HIP_TRY(d_box.alloc(BBOX_WORDS));
     PCR_TRY(device_bbox_launch<T>(ctx, d_xyz, n, d_box.p));
     unsigned h[7];
     HIP_TRY(hipMemcpyAsync(h, d_box, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
@@ -127,6 +155,17 @@ __device__ __forceinline__ uint32_t cell_of(const Geom<Real> &g, Real x, Real y,
     return (uint32_t)(((size_t)cz * g.ny + cy) * g.nx + cx);
 }
 
+// (thousands of blocks adding to ONE word serialise in its L2 channel: ~10 ns each, 41 us for the 4141 blocks of 1.06 M points --
+// the count goes to OCC_SLOTS words on separate cache lines and the host adds them up)
+#define OCC_SLOTS 64
+#define OCC_STRIDE 16
+#define OCC_WORDS (OCC_SLOTS * OCC_STRIDE)
+static unsigned long long occ_total(const unsigned long long *h) {
+    unsigned long long t = 0;
+    for (int i = 0; i < OCC_SLOTS; ++i) t += h[i * OCC_STRIDE];
+    return t;
+}
+
 // (occ: += the number of cells this launch touched first, i.e. the occupied cells of a histogram that started at zero -- one
 // atomic per block; a separate counting pass over the cells cost as much as this kernel, round 5)
 template <typename Real, typename T>
@@ -140,12 +179,46 @@ __global__ void __launch_bounds__(256) k_cell_ids(const T *__restrict__ xyz, int
     if (i < n) {
         const uint32_t c = cell_of<Real>(g, (Real)xyz[3 * i], (Real)xyz[3 * i + 1], (Real)xyz[3 * i + 2]);
         if (cell_id) { cell_id[i] = c; idx[i] = (uint32_t)i; }
-        first = atomicAdd(&counts[c], 1u) == 0u;
+        if (counts) first = atomicAdd(&counts[c], 1u) == 0u;
+    }
+    if (!counts) return;                 // (ids only: block-uniform)
+    const unsigned long long m = __ballot(first);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&firsts, (unsigned)__popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0 && firsts) atomicAdd(&occ[(blockIdx.x % OCC_SLOTS) * OCC_STRIDE], (unsigned long long)firsts);
+}
+
+// cell_start from the SORTED cell ids instead of an atomic histogram (the final pass' 1.06 M atomics on random cells took 58 us,
+// these two steps 10 + 20): head[c] = position of the first record of cell c (the array starts as all-ones, head[ncells] = n);
+// a reverse running minimum then gives every cell -- the empty ones included -- the position of the first record at or behind
+// it, which IS the exclusive prefix of the counts.  occ += the occupied cells.
+__global__ void __launch_bounds__(256) k_cell_heads(const uint32_t *__restrict__ cid, int64_t n, int64_t ncells, uint32_t *head,
+                                                    unsigned long long *occ) {
+    __shared__ unsigned firsts;
+    if (threadIdx.x == 0) firsts = 0;
+    __syncthreads();
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool first = false;
+    if (j < n) {
+        const uint32_t c = cid[j];
+        first = j == 0 || cid[j - 1] != c;
+        if (first) head[c] = (uint32_t)j;
+        if (j == 0) head[ncells] = (uint32_t)n;
     }
     const unsigned long long m = __ballot(first);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(&firsts, (unsigned)__popcll(m));
     __syncthreads();
-    if (threadIdx.x == 0 && firsts) atomicAdd(occ, (unsigned long long)firsts);
+    if (threadIdx.x == 0 && firsts) atomicAdd(&occ[(blockIdx.x % OCC_SLOTS) * OCC_STRIDE], (unsigned long long)firsts);
+}
+
+static pcr_status reverse_min_scan_u32(pcr_context *ctx, uint32_t *d_inout, int64_t n) {
+    auto it = rocprim::make_reverse_iterator(d_inout + n);
+    size_t tmp_bytes = 0;
+    HIP_TRY(rocprim::inclusive_scan(nullptr, tmp_bytes, it, it, (size_t)n, rocprim::minimum<uint32_t>(), ctx->stream));
+    DevBuf<char> tmp;
+    HIP_TRY(tmp.alloc_bytes(tmp_bytes));
+    HIP_TRY(rocprim::inclusive_scan(tmp.p, tmp_bytes, it, it, (size_t)n, rocprim::minimum<uint32_t>(), ctx->stream));
+    return PCR_OK;
 }
 
 __global__ void __launch_bounds__(256) k_gather_f32(const float *__restrict__ xyz, const uint32_t *__restrict__ order,
@@ -456,7 +529,8 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
 
     DevBuf<uint32_t> d_counts;
     DevBuf<unsigned long long> d_nz;
-    HIP_TRY(d_nz.alloc(1));
+    HIP_TRY(d_nz.alloc(OCC_WORDS));
+    std::vector<unsigned long long> h_nz(OCC_WORDS);
     double ncells = 0;
     int64_t occupied = 0;
     const unsigned nb = (unsigned)((n + 255) / 256);
@@ -471,13 +545,12 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
         }
         HIP_TRY(d_counts.alloc((size_t)ncells + 1));
         HIP_TRY(hipMemsetAsync(d_counts.p, 0, sizeof(uint32_t) * ((size_t)ncells + 1), ctx->stream));
-        HIP_TRY(hipMemsetAsync(d_nz.p, 0, sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(hipMemsetAsync(d_nz.p, 0, sizeof(unsigned long long) * OCC_WORDS, ctx->stream));
         hipLaunchKernelGGL((k_cell_ids<Real, T>), dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, g,
                            (uint32_t *)nullptr, (uint32_t *)nullptr, d_counts.p, d_nz.p);
-        unsigned long long nz = 0;
-        HIP_TRY(hipMemcpyAsync(&nz, d_nz.p, sizeof nz, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(h_nz.data(), d_nz.p, sizeof(unsigned long long) * OCC_WORDS, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        occupied = (int64_t)nz;
+        occupied = (int64_t)occ_total(h_nz.data());
         const double occ = (double)n / (double)(occupied > 0 ? occupied : 1);
         if (occ > 10.0 && dir <= 0 && !capped) { h *= 0.5; dir = -1; continue; }
         if (occ < 2.5 && dir >= 0) { h *= 2.0; dir = 1; continue; }
@@ -499,7 +572,7 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
     }
     *geom = g;
     HIP_TRY(d_counts.alloc_exact((size_t)ncells + 1));
-    HIP_TRY(hipMemsetAsync(d_counts.p, 0, sizeof(uint32_t) * ((size_t)ncells + 1), ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_counts.p, n > 0 ? 0xff : 0, sizeof(uint32_t) * ((size_t)ncells + 1), ctx->stream));
     DevBuf<uint32_t> d_cid, d_idx, d_cid2, d_idx2, d_seed;
     const size_t nn = (size_t)(n > 0 ? n : 1);
     HIP_TRY(d_cid.alloc(nn)); HIP_TRY(d_idx.alloc(nn));
@@ -508,11 +581,12 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
     HIP_TRY(d_pts.alloc_exact(nn + PCR_PTS_PAD));
     // sentinel records behind the last point (see nn_scan_range): +inf coordinates, index ~0
     hipLaunchKernelGGL(k_pad_sentinels<PT>, dim3(1), dim3(64), 0, ctx->stream, d_pts.p + (size_t)n);
-    HIP_TRY(hipMemsetAsync(d_nz.p, 0, sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_nz.p, 0, sizeof(unsigned long long) * OCC_WORDS, ctx->stream));
     if (n > 0) {
         hipLaunchKernelGGL((k_cell_ids<Real, T>), dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, g, d_cid.p, d_idx.p,
-                           d_counts.p, d_nz.p);
+                           (uint32_t *)nullptr, (unsigned long long *)nullptr);
         PCR_TRY(sort_pairs<uint32_t>(ctx, d_cid, d_cid2, d_idx, d_idx2, n, bits_for(ncells)));
+        hipLaunchKernelGGL(k_cell_heads, dim3(nb), dim3(256), 0, ctx->stream, (const uint32_t *)d_cid2.p, n, (int64_t)ncells, d_counts.p, d_nz.p);
         if (sizeof(Real) == 4)
             hipLaunchKernelGGL(k_gather_f32, dim3(nb), dim3(256), 0, ctx->stream, (const float *)d_xyz,
                                (const uint32_t *)d_idx2.p, n, (PtF *)d_pts.p);
@@ -520,14 +594,13 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
             hipLaunchKernelGGL(k_gather_f64, dim3(nb), dim3(256), 0, ctx->stream, (const double *)d_xyz,
                                (const uint32_t *)d_idx2.p, n, (PtD *)d_pts.p);
     }
-    PCR_TRY(exclusive_scan_u32(ctx, d_counts, (int64_t)ncells + 1));
+    if (n > 0) PCR_TRY(reverse_min_scan_u32(ctx, d_counts, (int64_t)ncells + 1));       // (n = 0: all zeros already)
     if (n > 0 && n < ((int64_t)1 << PCR_GAP_SHIFT)) {
         PCR_TRY(pack_gap_field(ctx, d_counts, g.nx, g.ny, g.nz, &d_seed.p));
         g.cs_mask = (1u << PCR_GAP_SHIFT) - 1u;
     }
     HIP_TRY(hipGetLastError());
     // (occupied cells of the final geometry: counted by k_cell_ids above, read back with the one synchronisation at the end)
-    unsigned long long nz2 = 0;
     const bool nz2_pending = n > 0;
     // ---- halo lists (point targets with a gap field: both share the 28-bit offsets)
     g.halo = (Real)0; g.cs_h = nullptr; g.pts_h = nullptr; g.j_h = nullptr; g.rowocc = nullptr; g.nyw = 0; g.nxb = 0;
@@ -541,9 +614,9 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
         if (n_h > 0) { g.halo = (Real)(fmin(halo_frac, 1.0) * (double)g.h); g.cs_h = d_cs_h.p; g.pts_h = d_pts_h.p; g.j_h = d_j_h.p; }
     }
     // (build_halo_lists synchronised for its total when it ran; otherwise once here: the index is complete when we return)
-    if (nz2_pending) HIP_TRY(hipMemcpyAsync(&nz2, d_nz.p, sizeof nz2, hipMemcpyDeviceToHost, ctx->stream));
+    if (nz2_pending) HIP_TRY(hipMemcpyAsync(h_nz.data(), d_nz.p, sizeof(unsigned long long) * OCC_WORDS, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (nz2_pending) occupied = (int64_t)nz2;
+    if (nz2_pending) occupied = (int64_t)occ_total(h_nz.data());
     // success: hand the index over
     g.seed = d_seed.p;
     *geom = g;
@@ -733,7 +806,10 @@ __global__ void __launch_bounds__(256) k_perm_pts64(const double *__restrict__ x
         if (!(d >= 0.0)) d = __longlong_as_double(0x7ff0000000000000LL);      // NaN: refuse (the caller checks for inf)
     }
     for (int off = 32; off >= 1; off >>= 1) d = fmax(d, __shfl_xor(d, off, 64));
-    if ((threadIdx.x & 63) == 0 && d > 0.0) atomicMax(dev, (unsigned long long)__double_as_longlong(d));
+    // (a wave only adds to the queue on one word when it can raise it: the maximum is monotone, a stale read costs an atomic)
+    if ((threadIdx.x & 63) == 0 && d > 0.0 &&
+        (unsigned long long)__double_as_longlong(d) > __hip_atomic_load(dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(dev, (unsigned long long)__double_as_longlong(d));
 }
 
 pcr_status pcr_attach_points_f64(pcr_context *ctx, pcr_target *t, const double *d_xyz64) {
@@ -857,7 +933,7 @@ pcr_status pcr_sort_scan(pcr_context *ctx, const float *d_xyz, int64_t n, unsign
     if (n == 0) return PCR_OK;
     const unsigned nb = (unsigned)((n + 255) / 256);
     DevBuf<unsigned> d_box;
-    HIP_TRY(d_box.alloc(7));
+    HIP_TRY(d_box.alloc(BBOX_WORDS));
     PCR_TRY(device_bbox_launch<float>(ctx, d_xyz, n, d_box.p));
     DevBuf<unsigned long long> k1, k2;
     DevBuf<uint32_t> i1, i2;
