@@ -538,9 +538,9 @@ pcr_status pcr_ensure_scratch(pcr_context *ctx, int64_t n_points) {
         HIP_TRY(hipHostMalloc(&ctx->h_out, sizeof(double) * 64, hipHostMallocMapped | hipHostMallocCoherent));
         memset(ctx->h_out, 0, sizeof(double) * 64);
         HIP_TRY(hipHostGetDevicePointer((void **)&ctx->h_out_dev, ctx->h_out, 0));
-        // 8 + 1 tickets (64 B apart), then the tile counters
+        // 8 + 1 tickets (a 128-byte line each), then the tile counters
         // ... then the word of k_nn_fix (the stamp of the last filter pass that left work for it)
-        const size_t ctr_words = 9 * 16 + (size_t)PCR_TILE_CTRS * PCR_TILE_STRIDE + 16;
+        const size_t ctr_words = 9 * PCR_TICKET_STRIDE + (size_t)PCR_TILE_CTRS * PCR_TILE_STRIDE + 16;
         HIP_TRY(pcr_malloc_retry((void **)&ctx->d_tile_ctr, sizeof(uint32_t) * ctr_words));
         HIP_TRY(hipMemsetAsync(ctx->d_tile_ctr, 0, sizeof(uint32_t) * ctr_words, ctx->stream));
 #ifdef PCR_DEV
@@ -715,8 +715,8 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
     a.flags = flags;
     a.nblocks = choose_blocks(ctx, s->n);
     a.partials = ctx->d_partials;
-    a.nn_j = s->nn_j; a.tile_ctr = ctx->d_tile_ctr + 9 * 16;
-    a.pending = ctx->d_tile_ctr + 9 * 16 + (size_t)PCR_TILE_CTRS * PCR_TILE_STRIDE;
+    a.nn_j = s->nn_j; a.tile_ctr = ctx->d_tile_ctr + 9 * PCR_TICKET_STRIDE;
+    a.pending = ctx->d_tile_ctr + 9 * PCR_TICKET_STRIDE + (size_t)PCR_TILE_CTRS * PCR_TILE_STRIDE;
     a.lb2 = s->lb2; a.umask = s->umask; a.ucnt = s->ucnt;
     a.mu_f = (float)(ctx->reuse_mu * (t->is_voxel ? t->gd.h : (double)t->gf.h));
     if (!one_kernel && a.nblocks > ctx->num_cu * 4) a.nblocks = ctx->num_cu * 4;   // k_reduce streams: 4 blocks/CU
@@ -737,7 +737,7 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
     f.local_len = ctx->local_frac * (t->is_voxel ? t->gd.h : (double)t->gf.h);
     f.deep_len = PCR_HALO2_MOVE * (t->is_voxel ? t->gd.h : (double)t->gf.h);
     f.ucnt = s->ucnt; f.n_ucnt = a.nblocks;
-    f.partials = ctx->d_partials; f.tile_ctr = ctx->d_tile_ctr + 9 * 16; f.tickets = ctx->d_tile_ctr; f.nblocks = a.nblocks; f.kind = kind; f.out = ctx->d_out;
+    f.partials = ctx->d_partials; f.tile_ctr = ctx->d_tile_ctr + 9 * PCR_TICKET_STRIDE; f.tickets = ctx->d_tile_ctr; f.nblocks = a.nblocks; f.kind = kind; f.out = ctx->d_out;
     return PCR_OK;
 }
 

@@ -447,7 +447,10 @@ __device__ __forceinline__ void linearize_body(const LinArgs &a, const PoseK &P,
 #define PCR_TILE_CTRS 64       // measured on MI355X (1.06 M queries, skeleton without the search): 8 counters
 #endif                         // and no static round 64 us, 8 + static 45, 64: 34, 64 + static 31, no counters 7
 #ifndef PCR_TILE_STRIDE
-#define PCR_TILE_STRIDE 16
+#define PCR_TILE_STRIDE 32
+#endif
+#ifndef PCR_TICKET_STRIDE
+#define PCR_TICKET_STRIDE 32         // words between the tickets of k_reduce_finalize's fold: a 128-byte line each
 #endif
 #ifndef PCR_TILE_STATIC_ROUNDS
 #define PCR_TILE_STATIC_ROUNDS 1   // 2 static rounds already unbalance the far poses (whole kernel 127 -> 155 us)
@@ -901,7 +904,7 @@ __device__ __forceinline__ bool ticket_fold_emit(double *acc, const LinArgs &a, 
     __shared__ double tot[32];
     const int ng = 8;          // (a single group for small grids was measured: no gain, 15.9 vs 15.7 us at 100 k points)
     const int g = (int)(blockIdx.x & 7), per = f.nblocks / ng;
-    uint32_t *ctr1 = &f.tickets[g * 16], *ctr2 = &f.tickets[8 * 16];
+    uint32_t *ctr1 = &f.tickets[g * PCR_TICKET_STRIDE], *ctr2 = &f.tickets[8 * PCR_TICKET_STRIDE];
     double *rows = const_cast<double *>(f.partials);
     // Hand-off protocol (MI355X guide, "sc1 payload -> drained vmcnt -> sc1 flag"): the 32 partial sums
     // were stored write-through at agent scope by lanes 0..31 of THIS wave; the explicit s_waitcnt below
