@@ -5,10 +5,11 @@
 //                               target point, covariance of the neighbours, eigenvector of the
 //                               smallest eigenvalue
 //
-// One lane = one query.  The running top-k list (squared distance, cell-sorted index) lives in
-// LDS, laid out [slot][lane] so a wave's accesses to one slot hit 64 different banks.  The search
-// is the ring expansion of nn_device.h with the k-th best distance as the pruning bound; ties are
-// ordered by (distance, original index), the oracle's rule (orc_knn_brute_f32).
+// One lane = one query; ties are ordered by (distance, original index), the oracle's rule (orc_knn_brute_f32).
+//   k <= 16   knn_collect: class counts over the 27-cell block bound the k-th distance, the points within the bound are
+//             queued unordered in LDS ([slot][lane]: a wave's accesses to one slot hit 64 banks) and ranked; queries it
+//             cannot answer (sparse neighbourhoods, overfull classes) take the ring search with the register list KnnReg
+//   k >  16   the ring expansion of nn_device.h with a sorted list in LDS (KnnList), the k-th best distance as the bound
 #include "eigen3.h"
 #include "nn_device.h"
 
