@@ -6,8 +6,8 @@
 //   grouping  rocPRIM radix sort of (key, point index) + run-length encode: voxels come out in
 //             ascending key order (np.unique) and, the sort being stable, every voxel's points in
 //             ascending point index (np.bincount's accumulation order)
-//   stats     k_voxel_stats    one wave per voxel: float64 mean, two-pass sample covariance
-//                              / max(n-1, 1), smallest-eigenvector normal, closed-form inverse
+//   stats     k_voxel_stats    one wave per voxel: float64 mean, two-pass sample covariance / max(n-1, 1)
+//             k_voxel_eig      one lane per kept voxel: smallest-eigenvector normal, closed-form inverse
 //   index     pcr_voxel_target_finish: dense grid over the kept centroids (float64 search)
 #include <hipcub/hipcub.hpp>
 
@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(256) k_voxel_stats(const T *__restrict__ xyz, 
                                                      const uint32_t *__restrict__ counts,
                                                      const uint32_t *__restrict__ seg_start,
                                                      const uint32_t *__restrict__ keep_pos, int64_t nu, int min_points,
-                                                     long long key_bias, double *mean, double *cov, double *norm, double *icov,
+                                                     long long key_bias, double *mean, double *cov,
                                                      int64_t *out_counts, int64_t *out_keys) {
     __shared__ double buf[4][3][VS_CHUNK];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -104,15 +104,27 @@ __global__ void __launch_bounds__(256) k_voxel_stats(const T *__restrict__ xyz, 
     double m9[9] = {c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5]};
 #pragma unroll
     for (int a = 0; a < 9; ++a) cov[9 * (size_t)o + a] = m9[a];
-    double nv[3];
-    smallest_eigvec3(c6, nv);                                                      // voxel.py:157-158
-    norm[3 * (size_t)o] = nv[0]; norm[3 * (size_t)o + 1] = nv[1]; norm[3 * (size_t)o + 2] = nv[2];
-    double ic[9];
-    icov_closed_form(m9, ic);                                                      // voxel.py:69-102
-#pragma unroll
-    for (int a = 0; a < 9; ++a) icov[9 * (size_t)o + a] = ic[a];
     out_counts[o] = (int64_t)cnt;
     out_keys[o] = ukeys[v] - key_bias;
+}
+
+// normal (smallest eigenvector, voxel.py:157-158) and closed-form inverse (voxel.py:69-102) of every kept voxel's covariance:
+// one LANE per voxel.  (Round 5: k_voxel_stats used to end with these -- a few hundred float64 instructions on lane 0 of a
+// wave per voxel, most of the kernel's 116 us per 1.06 M points.)
+__global__ void __launch_bounds__(256) k_voxel_eig(const double *__restrict__ cov, int64_t nk, double *norm, double *icov) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= nk) return;
+    double m9[9];
+#pragma unroll
+    for (int a = 0; a < 9; ++a) m9[a] = cov[9 * (size_t)o + a];
+    const double c6[6] = {m9[0], m9[1], m9[2], m9[4], m9[5], m9[8]};
+    double nv[3];
+    smallest_eigvec3(c6, nv);
+    norm[3 * (size_t)o] = nv[0]; norm[3 * (size_t)o + 1] = nv[1]; norm[3 * (size_t)o + 2] = nv[2];
+    double ic[9];
+    icov_closed_form(m9, ic);
+#pragma unroll
+    for (int a = 0; a < 9; ++a) icov[9 * (size_t)o + a] = ic[a];
 }
 
 template <typename T>
@@ -185,8 +197,11 @@ static pcr_status voxel_build(pcr_context *ctx, const T *d_xyz, int64_t n, doubl
         HIP_TRY(pcr_persist_alloc((void **)&t->st_counts, 8 * kk)); HIP_TRY(pcr_persist_alloc((void **)&t->st_keys, 8 * kk));
         if (nu > 0) {
             hipLaunchKernelGGL(k_voxel_stats<T>, dim3((unsigned)((nu + 3) / 4)), dim3(256), 0, ctx->stream, d_xyz, i2.p,
-                               ukeys.p, counts.p, seg.p, flags.p, nu, min_points, key_bias, t->st_mean, t->st_cov, t->st_norm, t->st_icov,
+                               ukeys.p, counts.p, seg.p, flags.p, nu, min_points, key_bias, t->st_mean, t->st_cov,
                                t->st_counts, t->st_keys);
+            if (nk > 0)
+                hipLaunchKernelGGL(k_voxel_eig, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, ctx->stream, (const double *)t->st_cov, nk,
+                                   t->st_norm, t->st_icov);
             HIP_TRY(hipGetLastError());          // (no synchronisation: the centroid grid is built on the same stream)
         }
         t->n = nk;
