@@ -84,6 +84,12 @@ CONFIGS = {
                        "cropped to x in [24, 144] m: 30 % of the scan overlaps the map"),
     "plane_100m_resampled": ("plane", 100_000_000, 12_500_000, None,
                              "Point-to-Plane ICP, synthetic 100M-pt target vs an independent 12.5M-pt sample of the same surfaces"),
+    # NON-UNIFORM density: one revolution of a 64-beam LiDAR standing in the same street -- density falls
+    # like 1/r^2, the ground is a set of ring lines, most of space is empty (synthetic.lidar_sweep).  Scan protocols as above.
+    "plane_lidar": ("plane", 1_060_000, 1_060_000, None,
+                    "Point-to-Plane ICP, lidar_sweep(1.06M) map (density ~ 1/r^2) vs its full perturbed scan"),
+    "icp_lidar_harness": ("icp", 1_060_000, 100_000, None,
+                          "Point-to-Point ICP, lidar_sweep(1.06M) map, reference-harness scan (100k points, t=(0,0,0.3) + noise)"),
 }
 SCAN_FAMILY = {"plane_b01_resampled": "resampled", "plane_b01_crop": "crop", "plane_100m_resampled": "resampled"}
 
@@ -239,8 +245,10 @@ def kernel_source_hash():
     return "src:" + h.hexdigest()[:16]
 
 
-def make_cloud(n, seed):
-    from point_cloud_registration_amd.synthetic import street, street_tiled
+def make_cloud(n, seed, config=""):
+    from point_cloud_registration_amd.synthetic import street, street_tiled, lidar_sweep
+    if "lidar" in config:
+        return lidar_sweep(n, seed=seed)
     return street(n, seed=seed) if n <= 2_000_000 else street_tiled(n, seed=seed)
 
 
@@ -328,7 +336,7 @@ def main():
             n_scan = n_target
         data_tag = "B-01.pcd"
     else:
-        target = make_cloud(n_target, seed=0)
+        target = make_cloud(n_target, seed=0, config=args.config)
     strong = args.scaling == "strong"
     sseed = 0 if strong else rank                              # strong: every rank builds the SAME scan, keeps a shard
     scan, T_true = make_scan(args.config, target, n_scan, seed=2 + sseed)

@@ -452,7 +452,7 @@ static void target_free(pcr_target *t) { pcr_target_release(t); }
 void pcr_target_release(pcr_target *t) {
     if (!t) return;
     target_free(t->filter);
-    void *ptrs[] = {t->cell_start, t->cell_seed, t->rowocc, t->cs_h, t->pts_h, t->j_h, t->cs_h2, t->pts_h2, t->j_h2, t->pts, t->pn, t->pts64, t->means, t->vnorm, t->vicov,
+    void *ptrs[] = {t->cell_start, t->cell_seed, t->rowocc, t->rbox, t->cs_h, t->pts_h, t->j_h, t->cs_h2, t->pts_h2, t->j_h2, t->pts, t->pn, t->pts64, t->means, t->vnorm, t->vicov,
                     t->st_mean, t->st_cov, t->st_norm, t->st_icov, t->st_counts, t->st_keys};
     if (t->ctx) (void)hipSetDevice(t->ctx->device);
     for (void *p : ptrs) pcr_persist_free(t->ctx, p);

@@ -421,7 +421,7 @@ static bool make_geom(const float lo[3], const float hi[3], double h, Geom<Real>
     g->slack = (Real)(16.0 * eps * (mag + h) + 1e-30);
     g->cs_mask = 0xffffffffu;
     g->seed = nullptr;
-    g->halo = (Real)0; g->cs_h = nullptr; g->pts_h = nullptr; g->j_h = nullptr; g->rowocc = nullptr; g->nyw = 0; g->nxb = 0;
+    g->halo = (Real)0; g->cs_h = nullptr; g->pts_h = nullptr; g->j_h = nullptr; g->rowocc = nullptr; g->nyw = 0; g->nxb = 0; g->rbox = nullptr; g->nxr = 0;
     return true;
 }
 
@@ -603,7 +603,7 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
     // (occupied cells of the final geometry: counted by k_cell_ids above, read back with the one synchronisation at the end)
     const bool nz2_pending = n > 0;
     // ---- halo lists (point targets with a gap field: both share the 28-bit offsets)
-    g.halo = (Real)0; g.cs_h = nullptr; g.pts_h = nullptr; g.j_h = nullptr; g.rowocc = nullptr; g.nyw = 0; g.nxb = 0;
+    g.halo = (Real)0; g.cs_h = nullptr; g.pts_h = nullptr; g.j_h = nullptr; g.rowocc = nullptr; g.nyw = 0; g.nxb = 0; g.rbox = nullptr; g.nxr = 0;
     DevBuf<uint32_t> d_cs_h, d_j_h;
     DevBuf<PtF> d_pts_h;
     int64_t n_h = 0;
@@ -663,6 +663,59 @@ static pcr_status make_row_occ(pcr_context *ctx, const uint32_t *cs, Geom<Real> 
     return PCR_OK;
 }
 
+// row-block boxes (Geom::rbox): one thread per record = the points of 8 consecutive cells of one row.  Coordinates relative to
+// the block are formed exactly as the search forms the query's (nn_rings_box): (p - origin) * (256 / h) - 256 * cell -- the
+// factor is the cell assignment's (p - origin) * inv_h scaled by a power of two, so a point sits in [0, 256) of its own cell.
+__global__ void __launch_bounds__(256) k_row_boxes(const PtF *__restrict__ pts, const uint32_t *__restrict__ cs, Geom<float> g, int64_t total,
+                                                   uint2 *__restrict__ out) {
+    const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= total) return;
+    const int xb = (int)(w % g.nxr);
+    const int64_t row = w / g.nxr;                          // = z * ny + y
+    const int y = (int)(row % g.ny), z = (int)(row / g.ny);
+    const int x0 = xb << PCR_RB_LOG, x1 = min(x0 + (1 << PCR_RB_LOG), g.nx);
+    const size_t base = (size_t)row * (size_t)g.nx;
+    uint32_t s[(1 << PCR_RB_LOG) + 1];
+    uint32_t occ = 0;
+#pragma unroll
+    for (int c = 0; c <= (1 << PCR_RB_LOG); ++c) s[c] = cs[base + (size_t)min(x0 + c, x1)] & g.cs_mask;
+#pragma unroll
+    for (int c = 0; c < (1 << PCR_RB_LOG); ++c) occ |= (s[c + 1] != s[c] ? 1u : 0u) << c;
+    if (occ == 0) { out[w] = make_uint2(0u, 0u); return; }
+    const float qs = 256.f * g.inv_h, qx = 32.f * g.inv_h;
+    const float bx = (float)x0 * 32.f, by = (float)y * 256.f, bz = (float)z * 256.f;
+    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+    for (uint32_t j = s[0]; j < s[1 << PCR_RB_LOG]; ++j) {
+        const PtF p = pts[j];
+        const float rx = (p.x - g.ox) * qx - bx, ry = (p.y - g.oy) * qs - by, rz = (p.z - g.oz) * qs - bz;
+        lo[0] = fminf(lo[0], rx); hi[0] = fmaxf(hi[0], rx);
+        lo[1] = fminf(lo[1], ry); hi[1] = fmaxf(hi[1], ry);
+        lo[2] = fminf(lo[2], rz); hi[2] = fmaxf(hi[2], rz);
+    }
+    uint32_t b[6];
+    for (int a = 0; a < 3; ++a) {
+        b[2 * a] = (uint32_t)fminf(fmaxf(floorf(lo[a]), 0.f), 255.f);
+        b[2 * a + 1] = (uint32_t)fminf(fmaxf(floorf(hi[a]), 0.f), 255.f);
+    }
+    out[w] = make_uint2(occ | (b[0] << 8) | (b[1] << 16) | (b[2] << 24), b[3] | (b[4] << 8) | (b[5] << 16));
+}
+
+static pcr_status make_row_boxes(pcr_context *ctx, pcr_target *t) {
+    Geom<float> &g = t->gf;
+    g.rbox = nullptr; g.nxr = (g.nx + (1 << PCR_RB_LOG) - 1) >> PCR_RB_LOG;
+    const int64_t total = (int64_t)g.nz * g.ny * g.nxr;
+    if (total <= 0 || t->n <= 0) return PCR_OK;
+    DevBuf<uint2> buf;
+    HIP_TRY(buf.alloc_exact((size_t)total));
+    hipLaunchKernelGGL(k_row_boxes, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const PtF *)t->pts,
+                       (const uint32_t *)t->cell_start, g, total, buf.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    t->rbox = buf.release();
+    g.rbox = t->rbox;
+    return PCR_OK;
+}
+
 pcr_status pcr_count_nonfinite(pcr_context *ctx, const void *d_xyz, int is_f64, int64_t n, int64_t *count, float *lo_out, float *hi_out) {
     float lo[3], hi[3];
     pcr_status s = is_f64 ? device_bbox<double>(ctx, (const double *)d_xyz, n, lo, hi, count)
@@ -688,6 +741,9 @@ pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n,
     if (he && *he) halo = atof(he);
     PCR_TRY((build_grid<float, float, PtF>(ctx, d_xyz, n, h, auto_h, &t->gf, &t->cell_start, &t->cell_seed, &t->pts, &t->occupied,
                                            halo, &t->cs_h, &t->pts_h, &t->j_h, &t->n_h)));
+    // row-block boxes for the far search (round 6; PCR_RBOX=0: none -> the plain ring loop)
+    const char *re = use_env ? getenv("PCR_RBOX") : nullptr;
+    if (use_env && !(re && atoi(re) == 0)) PCR_TRY(make_row_boxes(ctx, t));      // (use_env = false: the filter index of a voxel target)
     return PCR_OK;       // (no row-occupancy bitmap for point targets: measured slower, nn_device.h)
 }
 
@@ -854,7 +910,7 @@ pcr_status pcr_attach_points_f64(pcr_context *ctx, pcr_target *t, const double *
     // position lies within band64 of its record
     g.slack = (double)gf.slack * 2.0 + t->band64;
     g.cs_mask = gf.cs_mask;
-    g.seed = nullptr; g.halo = 0; g.cs_h = nullptr; g.pts_h = nullptr; g.j_h = nullptr; g.rowocc = nullptr; g.nyw = 0; g.nxb = 0;
+    g.seed = nullptr; g.halo = 0; g.cs_h = nullptr; g.pts_h = nullptr; g.j_h = nullptr; g.rowocc = nullptr; g.nyw = 0; g.nxb = 0; g.rbox = nullptr; g.nxr = 0;
     return PCR_OK;
 }
 

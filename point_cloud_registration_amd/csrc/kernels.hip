@@ -168,7 +168,7 @@ __device__ __forceinline__ void nn_chunk_loop(const LinArgs &a, Body &&body) {
 #ifndef PCR_VOX_WAVES
 #define PCR_VOX_WAVES 4
 #endif
-template <int VOXEL, int HALO, int LOCAL, int MODE>
+template <int VOXEL, int HALO, int LOCAL, int MODE, int RB = 0>
 __global__ void __launch_bounds__(256, VOXEL == 2 ? PCR_VOX_WAVES : 5) k_nn_scan(const LinArgs a) {
     PoseK P;
     PoseQ Q;
@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(256, VOXEL == 2 ? PCR_VOX_WAVES : 5) k_nn_scan
         const Geom<float> gsel = (!VOXEL && HALO && LOCAL == 2) ? select_lists(a) : a.gf;
         auto body = [&](int64_t first, int64_t end) {
             const int64_t i = first + (threadIdx.x & 63);
-            if (i < end) nn_point<VOXEL, HALO, MODE == PCR_NN_TRACK>(a, gsel, P, Q, i);
+            if (i < end) nn_point<VOXEL, HALO, MODE == PCR_NN_TRACK, RB>(a, gsel, P, Q, i);
         };
         if (LOCAL == 2) {       // device-resident loop: k_gn_update decided from the size of its step (PoseDev::tile_local)
             if (__builtin_amdgcn_readfirstlane(a.pose->tile_local)) nn_tile_loop<1, 64>(a, body);
@@ -285,7 +285,11 @@ static void launch_nn_filter(bool halo, int local, bool separate_fix, bool q6, d
 template <int VOXEL, int MODE>
 static void launch_nn_scan_mode(bool halo, int local, dim3 grid, hipStream_t st, const LinArgs &a) {
     const dim3 block(256);
-#define PCR_NN_CASE(H, L) hipLaunchKernelGGL((k_nn_scan<VOXEL, (VOXEL ? 0 : H), L, MODE>), grid, block, 0, st, a)
+    // (RB: plain full searches of a point target that carries row-block boxes, Geom::rbox)
+    constexpr bool can_rb = VOXEL == 0 && MODE == PCR_NN_FULL;
+    const bool rb = can_rb && a.gf.rbox != nullptr;
+#define PCR_NN_CASE(H, L) do { if (rb) hipLaunchKernelGGL((k_nn_scan<VOXEL, (VOXEL ? 0 : H), L, MODE, can_rb ? 1 : 0>), grid, block, 0, st, a); \
+                               else hipLaunchKernelGGL((k_nn_scan<VOXEL, (VOXEL ? 0 : H), L, MODE, 0>), grid, block, 0, st, a); } while (0)
     if (MODE == PCR_NN_FULL && local == 2) { if (halo) PCR_NN_CASE(1, 2); else PCR_NN_CASE(0, 2); return; }
     if (halo) { if (local) PCR_NN_CASE(1, 1); else PCR_NN_CASE(1, 0); }
     else { if (local) PCR_NN_CASE(0, 1); else PCR_NN_CASE(0, 0); }
@@ -550,6 +554,11 @@ pcr_status pcr_ensure_scratch(pcr_context *ctx, int64_t n_points) {
             ctx->nn_blocks_per_cu[4] = (e == hipSuccess && nbm > 0) ? nbm : 2;
         }
 #endif
+        {
+            int nb = 0;
+            const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<0, 1, 0, 0, 1>, 256, 0);
+            ctx->nn_blocks_rb = (e == hipSuccess && nb > 0) ? nb : 4;
+        }
         for (int v = 0; v < 4; ++v) {
             int nb = 0;
             if (v == 2) {
@@ -862,6 +871,7 @@ static pcr_status pass_enqueue(Pass *ps) {
         {   // exactly one resident generation of waves; they share the tiles dynamically
             RoctxRange range("pcr:nn_search");
             int64_t nb = (int64_t)ctx->num_cu * ctx->nn_blocks_per_cu[filter ? 3 : vox ? 1 : (ctx->nn_mode == 2 && !ps->q6 ? 2 : 0)];
+            if (!filter && !vox && mode == PCR_NN_FULL && a.gf.rbox != nullptr && ctx->nn_mode != 2) nb = (int64_t)ctx->num_cu * ctx->nn_blocks_rb;
             // tiles of the hand-out: 64 points per wave, or the 1024-point chunks of a LIST pass (one block per chunk)
             const int64_t tiles = mode == PCR_NN_LIST ? (a.n + PCR_LIST_CHUNK - 1) / PCR_LIST_CHUNK : (a.n + 63) / 64;
             const int64_t need = mode == PCR_NN_LIST ? tiles : (tiles + 3) / 4;

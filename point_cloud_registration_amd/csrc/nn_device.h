@@ -358,6 +358,104 @@ __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restri
 #undef PB
 }
 
+// ---- rings with TIGHT row-block boxes (round 6; float32 point targets that carry Geom::rbox) ----------------------------
+// The plain ring loop bounds a row of cells from below by the distance to the cells' CUBES.  A cloud is a set of surfaces: the
+// ground fills a few centimetres of the 40-cm layer of cells it lies in, so a query D above it sees "D - (up to) h" for
+// every cell of that layer, visits every row within sqrt(2 D h) of its foot point and tests their points (82 candidates and
+// 7.2 row segments per query at the first pose of plane_b01, of which the ball really contains a handful).  Here every
+// segment of a row first reads the box of the POINTS in its 8-cell block (one 8-byte record out of a table of 1 byte per cell:
+// cache-resident where cell_start is not), is skipped when that box lies beyond the current best, and otherwise is clipped
+// in x to the block's occupied cells and to what the ball leaves of the box's (y, z) distance.  Bounds stay conservative: a
+// bound byte stands for [b, b + 1), and `mq` (grid slack + 1.5 quantisation steps) is taken off every side.
+template <bool STATS = false, int B = PCR_NN_BATCH>
+__device__ __forceinline__ void nn_rings_box(const Geom<float> &g, const PtF *__restrict__ pts, const uint32_t *__restrict__ cs,
+                                             const NNCell<float> &c, int kstart, float qx, float qy, float qz,
+                                             float &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr) {
+    typedef RealTraits<float> RT;
+    const float lim = 1.0e9f;
+    const int cx = c.cx, cy = c.cy, cz = c.cz;
+    const float fx = c.fx, fy = c.fy, fz = c.fz;
+    const uint32_t unx = (uint32_t)g.nx, plane = (uint32_t)g.ny * (uint32_t)g.nx;   // ncells < 2^32
+    const float qs = 256.f * g.inv_h;                   // quantisation steps per metre (y, z; an x step is 8 of them)
+    const float qs2 = qs * qs;
+    const float mq = g.slack * qs + 1.5f;
+    const float ux0 = (qx - g.ox) * qs, uy0 = (qy - g.oy) * qs, uz0 = (qz - g.oz) * qs;
+    // one segment [xl, xh] of row (y, z), cells at `row`; rrow = its first box record
+    auto segment = [&](uint32_t row, uint32_t rrow, float uy, float uz, int xl, int xh) __attribute__((always_inline)) {
+        for (int xb = xl >> PCR_RB_LOG; xb <= (xh >> PCR_RB_LOG); ++xb) {
+            const uint2 w = g.rbox[rrow + (uint32_t)xb];
+            const int x0 = xb << PCR_RB_LOG;
+            const int lo = max(xl - x0, 0), hi = min(xh - x0, (1 << PCR_RB_LOG) - 1);
+            uint32_t m = (w.x & 0xffu) & (0xffu << lo) & (0xffu >> (7 - hi));
+            if (m == 0) { if (STATS) st->rows_pruned++; continue; }
+            const float ux = ux0 - (float)x0 * 256.f;                            // the query from the block's corner, y / z steps
+            const float xlo = (float)((w.x >> 8) & 0xffu) * 8.f, xhi = (float)((w.x >> 16) & 0xffu) * 8.f + 8.f;
+            const float ylo = (float)(w.x >> 24), yhi = (float)(w.y & 0xffu) + 1.f;
+            const float zlo = (float)((w.y >> 8) & 0xffu), zhi = (float)((w.y >> 16) & 0xffu) + 1.f;
+            const float dx = fmaxf(fmaxf(xlo - ux, ux - xhi) - mq, 0.f);
+            const float dy = fmaxf(fmaxf(ylo - uy, uy - yhi) - mq, 0.f);
+            const float dz = fmaxf(fmaxf(zlo - uz, uz - zhi) - mq, 0.f);
+            const float dyz = dy * dy + dz * dz;
+            const float pbq = best * qs2;
+            if (dyz + dx * dx > pbq) { if (STATS) st->rows_pruned++; continue; }
+            if (pbq < RT::inf()) {                          // what the ball leaves of the box's (y, z) distance, in cells of this block
+                const float xr = RT::sqrt_fast(pbq - dyz) * 1.000002f + mq;
+                const float a = (ux - xr) * (1.f / 256.f), b = (ux + xr) * (1.f / 256.f);
+                const int la = a > 0.f ? (int)fminf(a, 8.f) : 0, hb = b < 8.f ? (b < 0.f ? -1 : (int)b) : 7;
+                m &= (0xffu << la) & (hb >= 0 ? (0xffu >> (7 - hb)) : 0u);
+                if (m == 0) { if (STATS) st->rows_pruned++; continue; }
+            }
+            const int l2 = __builtin_ctz(m), h2 = 31 - __builtin_clz(m);
+            const uint32_t s_ = cs[row + (uint32_t)(x0 + l2)] & g.cs_mask, e_ = cs[row + (uint32_t)(x0 + h2) + 1u] & g.cs_mask;
+            if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
+            nn_scan_range<float, PtF, 0, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, nullptr);
+        }
+    };
+    for (int k = kstart; k <= c.kmax; ++k) {
+        if (nn_certified<float>(g, c, k, best)) break;
+        if (STATS) st->rings++;
+        const int zlo = max(cz - k, 0), zhi = min(cz + k, g.nz - 1);
+        const int ylo = max(cy - k, 0), yhi = min(cy + k, g.ny - 1);
+        const int xlo = max(cx - k, 0), xhi = min(cx + k, g.nx - 1);
+        const int xa = cx - k, xb = cx + k;
+        const bool xa_in = xa >= 0 && xa < g.nx, xb_in = xb >= 0 && xb < g.nx;
+        float dxa = fmaxf((float)(k - 1) * g.h + fx - g.slack, 0.f), dxb = fmaxf((float)k * g.h - fx - g.slack, 0.f);
+        dxa *= dxa; dxb *= dxb;
+        for (int z = zlo; z <= zhi; ++z) {
+            const int dzc = z - cz;
+            float dzm = dzc == 0 ? 0.f : (dzc > 0 ? (float)dzc * g.h - fz : (float)(-dzc - 1) * g.h + fz);
+            dzm = fmaxf(dzm - g.slack, 0.f);
+            const float dz2 = dzm * dzm;
+            if (dz2 > best) continue;
+            const bool zshell = (dzc == k) || (dzc == -k);
+            const float uz = uz0 - (float)z * 256.f;
+            uint32_t row = (uint32_t)z * plane + (uint32_t)ylo * unx;
+            uint32_t rrow = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)ylo) * (uint32_t)g.nxr;
+            for (int y = ylo; y <= yhi; ++y, row += unx, rrow += (uint32_t)g.nxr) {
+                const int dyc = y - cy;
+                float dym = dyc == 0 ? 0.f : (dyc > 0 ? (float)dyc * g.h - fy : (float)(-dyc - 1) * g.h + fy);
+                dym = fmaxf(dym - g.slack, 0.f);
+                const float dyz2 = dz2 + dym * dym;
+                if (dyz2 > best) { if (STATS) st->rows_pruned++; continue; }
+                const float uy = uy0 - (float)y * 256.f;
+                if (zshell || dyc == k || dyc == -k) {
+                    int xl = xlo, xh = xhi;
+                    if (best < RT::inf()) {                 // clip the row to the remaining budget (cube bound; the box clips again)
+                        const float xr = RT::sqrt_fast(best - dyz2) * 1.000002f + g.slack;
+                        const float a = (qx - xr - g.ox) * g.inv_h, b = (qx + xr - g.ox) * g.inv_h;
+                        if (a > (float)xl) xl = (int)RT::floor_(fminf(a, lim));
+                        if (b < (float)xh) xh = (int)RT::floor_(fmaxf(b, -lim));
+                    }
+                    if (xl <= xh) segment(row, rrow, uy, uz, xl, xh);
+                } else {                                    // interior row of the ring: its two end cells
+                    if (xa_in && dyz2 + dxa <= best) segment(row, rrow, uy, uz, xa, xa);
+                    if (xb_in && dyz2 + dxb <= best) segment(row, rrow, uy, uz, xb, xb);
+                }
+            }
+        }
+    }
+}
+
 // The same rings with the rows of a slab taken from the row-occupancy bitmap (Geom::rowocc): the centroid search when
 // the gate spans >= 5 rings (kernels.hip: k_nn_scan<VOXEL = 2>).  A separate function on purpose: routing the plain
 // search through the shared row body (a lambda) cost the 1e8-point search 5-13 % (74.5 / 80.5 vs 70.9 ms per 26 passes).
@@ -462,7 +560,7 @@ __device__ __forceinline__ void nn_rings_occ(const Geom<Real> &g, const PT *__re
 // TRACK: `tk` was initialised with nn_track_init(tk, bound2, mu); on return min(tk->second, tk->pmin) is a lower
 // bound on the squared distance to every target point other than the winner (to every point if there is none).
 template <typename Real, typename PT, bool STATS = false, bool SEEDED = false, bool HALO = false, int TRACK = 0, bool OCC = false,
-          int B = PCR_NN_BATCH>
+          int B = PCR_NN_BATCH, bool RBOX = false>
 __device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restrict__ pts,
                                           const uint32_t *__restrict__ cs,
                                           Real qx, Real qy, Real qz, Real bound2,
@@ -471,7 +569,10 @@ __device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restr
     if (!SEEDED) { best = bound2; bj = PCR_NONE; borig = PCR_NONE; }
     NNCell<Real> c = nn_cell<Real>(g, qx, qy, qz, bound2);
     const int kstart = nn_ring0<Real, PT, STATS, HALO, TRACK, B>(g, pts, cs, c, qx, qy, qz, best, bj, borig, st, tk);
-    if (OCC) nn_rings_occ<Real, PT, STATS, TRACK>(g, pts, cs, c, kstart, qx, qy, qz, best, bj, borig, st, tk);
+    if constexpr (RBOX) {
+        static_assert(sizeof(Real) == 4 && TRACK == 0 && !OCC, "row-block boxes: plain float32 point search only");
+        nn_rings_box<STATS, B>(g, pts, cs, c, kstart, qx, qy, qz, best, bj, borig, st);
+    } else if (OCC) nn_rings_occ<Real, PT, STATS, TRACK>(g, pts, cs, c, kstart, qx, qy, qz, best, bj, borig, st, tk);
     else nn_rings<Real, PT, STATS, TRACK, B>(g, pts, cs, c, kstart, qx, qy, qz, best, bj, borig, st, tk);
 }
 

@@ -600,7 +600,8 @@ __device__ __forceinline__ void nn_tile_loop(const LinArgs &a, Body &&body) {
 // distance from the transformed point to every other target point, for k_certify of the next pass.  A point
 // that moved less than mu since the previous pass searches up to mu beyond its match to make that bound useful;
 // one that moved more searches exactly like the plain kernel (its bound then carries no margin).
-template <int VOXEL, int HALO, int TRACK>
+// RB (round 6): the rings of a plain point search prune by the target's row-block boxes (nn_rings_box)
+template <int VOXEL, int HALO, int TRACK, int RB = 0>
 __device__ __forceinline__ void nn_point(const LinArgs &a, const Geom<float> &gf, const PoseK &P, const PoseQ &Q, int64_t i) {
     const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
     float tx, ty, tz;
@@ -632,7 +633,7 @@ __device__ __forceinline__ void nn_point(const LinArgs &a, const Geom<float> &gf
             if (pj != PCR_NONE) nn_test<float, PtF, 0>(a.pts[pj], pj, tx, ty, tz, best, bj, bo);
             nn_search<float, PtF, false, true, HALO != 0, false>(gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
 #else
-            nn_search<float, PtF, false, false, HALO != 0, false>(gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
+            nn_search<float, PtF, false, false, HALO != 0, false, false, PCR_NN_BATCH, RB != 0>(gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
 #endif
             lb2q = best;
         }

@@ -62,7 +62,16 @@ struct Geom {
     // point in cells [16 (x >> 4), 16 (x >> 4) + 16): lets the wide rings of a far query skip empty rows 64 at a time
     const unsigned long long *rowocc;
     int nyw, nxb;
+    // row-block boxes (float32 point targets, nullptr = none; round 6): record ((z * ny + y) * nxr + (x >> 3)) describes the
+    // points in cells [8 (x >> 3), 8 (x >> 3) + 8) of row (y, z): .x = occupancy of the 8 cells (byte 0) | x_lo (byte 1) |
+    // x_hi (byte 2) | y_lo (byte 3), .y = y_hi (byte 0) | z_lo (byte 1) | z_hi (byte 2).  x bounds in units of h / 32 from the
+    // block's first cell, y / z bounds in units of h / 256 from the row's cell; a bound byte b stands for [b, b + 1).  The
+    // far search (nn_device.h: nn_rings_box) prunes a row segment by its distance to this TIGHT box instead of to the cubes
+    // of its cells: clouds are surfaces, and a surface fills a small part of the cells it crosses.
+    const uint2 *rbox;
+    int nxr;
 };
+#define PCR_RB_LOG 3             // cells per row block = 8
 #ifndef PCR_HALO2_FRAC
 #define PCR_HALO2_FRAC 0.25      // margin of the deeper list set, x cell
 #endif
@@ -224,6 +233,7 @@ struct pcr_context {
     bool fuse_finalize = true;   // k_reduce_finalize (PCR_FUSE_FINALIZE=0: k_reduce + k_finalize)
     uint32_t *d_tile_ctr = nullptr;     // per-XCD dynamic tile counters of k_nn_scan
     int nn_blocks_per_cu[5] = {4, 4, 4, 4, 2};   // resident 256-thread blocks per CU of k_nn_scan<0/1>, k_nn_coop, k_nn_filter, k_nn_mfma
+    int nn_blocks_rb = 4;               // ... of k_nn_scan<0, ., ., FULL, RB = 1> (row-block boxes)
     uint32_t filter_stamp = 0;          // stamp of the last k_nn_filter pass (k_nn_fix)
     // profiling
     bool prof_on = false;
@@ -257,6 +267,7 @@ struct pcr_target {
     uint32_t *cell_start = nullptr;
     uint32_t *cell_seed = nullptr;
     unsigned long long *rowocc = nullptr;   // row-occupancy bitmap of the grid (Geom::rowocc)
+    uint2 *rbox = nullptr;                  // row-block boxes of a point target (Geom::rbox)
     uint32_t *cs_h = nullptr;        // extended (halo) lists of point targets
     PtF *pts_h = nullptr;
     uint32_t *j_h = nullptr;

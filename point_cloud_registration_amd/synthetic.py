@@ -94,6 +94,41 @@ def street_tiled(n_total, seed=0, per_tile=1_000_000):
     return out
 
 
+def lidar_sweep(n, seed=0, sensor=(-20.0, 5.0, 1.8), rings=64, elev_deg=(-24.8, 15.0),
+                range_limits=(0.5, 150.0), noise=0.02):
+    """One revolution of a spinning ``rings``-beam LiDAR standing in the ``street`` geometry (ground z = 0 over
+    x in [-60, 60], y in [-30, 30]; walls y = +-30 and x = +-60 up to z = 20): ``n`` float32 returns.
+
+    Unlike ``street`` (constant density) this is what a real scan -- and the reference's absent B-01 street scan
+    (``data/README.md:1-8``) -- looks like to a spatial index: point density falls like 1/r^2 with the range, the
+    ground is a set of concentric ring lines (hundreds of returns per metre of arc at 4 m, a few at 60 m), and most
+    of the space between the rings is empty.  Beams that leave the box through the open top give no return; azimuths
+    are drawn until ``n`` returns exist.  Range noise N(0, ``noise``) along the beam.
+    """
+    rng = np.random.default_rng(seed)
+    n = int(n)
+    s = np.asarray(sensor, dtype=np.float64)
+    elev = np.deg2rad(np.linspace(elev_deg[0], elev_deg[1], rings))
+    out = np.empty((0, 3), dtype=np.float64)
+    per_ring = max(16, int(np.ceil(n / rings * 1.6)))
+    while out.shape[0] < n:
+        az = (np.arange(per_ring) + rng.uniform(0.0, 1.0)) * (2.0 * np.pi / per_ring)
+        a, e = np.meshgrid(az, elev, indexing="ij")             # azimuth-major: returns interleave the rings like a real sweep
+        a = a.ravel() + rng.normal(0.0, 2.0e-4, a.size)
+        e = e.ravel()
+        d = np.stack([np.cos(e) * np.cos(a), np.cos(e) * np.sin(a), np.sin(e)], axis=1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t_ground = np.where(d[:, 2] < 0, -s[2] / d[:, 2], np.inf)
+            t_x = np.where(d[:, 0] > 0, (60.0 - s[0]) / d[:, 0], np.where(d[:, 0] < 0, (-60.0 - s[0]) / d[:, 0], np.inf))
+            t_y = np.where(d[:, 1] > 0, (30.0 - s[1]) / d[:, 1], np.where(d[:, 1] < 0, (-30.0 - s[1]) / d[:, 1], np.inf))
+        t = np.minimum(t_ground, np.minimum(t_x, t_y))
+        hit = s + d * t[:, None]
+        ok = np.isfinite(t) & (t >= range_limits[0]) & (t <= range_limits[1]) & (hit[:, 2] <= 20.0) & (hit[:, 2] >= -1e-9)
+        t = t[ok] + rng.normal(0.0, noise, int(ok.sum()))
+        out = np.concatenate([out, s + d[ok] * t[:, None]])
+    return np.ascontiguousarray(out[:n], dtype=np.float32)
+
+
 def make_T(so3, t):
     T = np.eye(4)
     T[:3, :3] = expSO3(np.asarray(so3, dtype=np.float64))

@@ -25,7 +25,7 @@ a = ap.parse_args()
 kind_name, n_target, n_scan, voxel_size, desc = B.CONFIGS[a.config]
 kind = {"icp": _capi.ICP, "plane": _capi.PLANE, "vplane": _capi.VPLANE, "ndt": _capi.NDT}[kind_name]
 ctx = _capi.get_context(0)
-target = B.make_cloud(n_target, seed=0)
+target = B.make_cloud(n_target, seed=0, config=a.config)
 scan, T_true = B.make_scan(a.config, target, n_scan, a.scan, seed=2)
 if kind_name in ("icp", "plane"):
     tgt = _capi.Target.points(ctx, target)
@@ -37,7 +37,7 @@ sc = _capi.Scan(ctx, scan)
 T_fin, iters, trace = _capi.align(tgt, sc, kind, np.eye(4), 30, 1e-3, 2.0, want_trace=True)
 traj = [trace[i, :16].reshape(4, 4).copy() for i in range(iters)]
 info = tgt.index_info()
-print(f"[{a.config}/{a.scan}] {iters} GN iterations, scan {sc.n}, index cell {info['cell']:.3f} halo {info['halo']:.3f}", flush=True)
+print(f"[{a.config}/{a.scan}] {iters} GN iterations, scan {sc.n}, index cell {info['cell']:.3f} halo {info['halo']:.3f} dims {info.get('dims')} occupied {info.get('occupied')}", flush=True)
 ctx.set_reuse(None, a.tau, a.mu)
 print("reuse settings", ctx.get_reuse(), flush=True)
 
