@@ -36,7 +36,7 @@ extern "C" {
 /* Bumped whenever an existing entry point changes its argument layout or the size of an array it writes
  * (4: PCR_K_COUNT 5 -> 6, i.e. pcr_profile_read writes six entries).  A binding compares it with
  * pcr_abi_version() of the library it loaded before calling anything else.                                   */
-#define PCR_ABI_VERSION 4
+#define PCR_ABI_VERSION 5
 
 typedef int pcr_status;
 enum {
@@ -46,7 +46,9 @@ enum {
     PCR_ERR_NO_TARGET = -3,   /* target lacks what the requested kind needs (normals / icov) */
     PCR_ERR_COMM = -4,        /* RCCL failure or communicator misuse */
     PCR_ERR_SINGULAR = -5,    /* pcr_align: H singular (zero correspondences); quirk Q7 */
-    PCR_ERR_NOMEM = -6
+    PCR_ERR_NOMEM = -6,
+    PCR_ERR_UNSUPPORTED = -7  /* an optional fast path is not available for this input (the target stays usable as it was):
+                                 pcr_target_points_set_f64 on coordinates float32 cannot resolve */
 };
 
 /* registration kinds: which reference class's calc_H_g_e2 is evaluated */
@@ -73,6 +75,9 @@ enum {
 typedef struct pcr_context pcr_context;
 typedef struct pcr_target pcr_target;
 typedef struct pcr_scan pcr_scan;
+typedef struct pcr_group pcr_group;                 /* single-process multi-device: one context + host thread per member */
+typedef struct pcr_group_target pcr_group_target;   /* the same target index on every member */
+typedef struct pcr_group_scan pcr_group_scan;       /* a scan cut into one contiguous shard per member */
 
 /* ---- library / context ------------------------------------------------------------ */
 PCR_API const char *pcr_last_error(void);
@@ -110,6 +115,45 @@ PCR_API pcr_status pcr_comm_destroy(pcr_context *ctx);
 PCR_API pcr_status pcr_comm_p2p_export(pcr_context *ctx, void *handle64);
 PCR_API pcr_status pcr_comm_p2p_attach(pcr_context *ctx, const void *handles, int nranks, int rank);
 PCR_API pcr_status pcr_comm_p2p_failed(pcr_context *ctx, int *failed);
+/* 1: this context's slots are fine-grained device memory (coherent across devices while a kernel runs); 0: the coarse-grained
+ * fallback, sound only between ranks that share ONE device -- ranks on different devices must agree on another transport
+ * (distributed.py does).  PCR_P2P_ALLOW_COARSE=0 makes pcr_comm_p2p_export fail instead of falling back.
+ * Since round 6 a timed-out exchange makes pcr_linearize / pcr_align of THAT rank return PCR_ERR_COMM (the device-resident
+ * loop stops on it) instead of NaN sums with PCR_OK.                                                                    */
+PCR_API pcr_status pcr_comm_p2p_finegrained(pcr_context *ctx, int *finegrained);
+
+/* ---- single-process multi-device groups ("pcr_init(device_ids, n_dev)"; the reference is one process:
+ * registration.py:28,71) ----
+ * pcr_group_create: one context + one host thread per entry of device_ids (1..8 entries; an id may repeat -- [0, 0] are two
+ * contexts on one GPU, which is how a one-GPU box exercises N > 1).  Targets are built once per member (the index is
+ * replicated), pcr_group_scan_create cuts the scan into contiguous, balanced shards (member i: points [lo_i, hi_i), the
+ * bounds of distributed.shard_bounds), and pcr_group_linearize / pcr_group_align run pcr_linearize / pcr_align on every
+ * member at once with the members' 29 sums exchanged through the peer-to-peer kernel above on in-process peer pointers
+ * (hipDeviceEnablePeerAccess; no IPC, no RCCL, no torch): every member takes the same Gauss-Newton step on bit-identical
+ * sums, and the call returns member 0's copy -- what the SPMD run with the same sharding returns, bit for bit.
+ * Calls on one group are serialised by the caller (like every other handle); errors: the first failing member's status,
+ * pcr_last_error() names the member.  PCR_FLAG_LOCAL_ONLY is ignored (a group call is the sum over its members).          */
+PCR_API pcr_status pcr_group_create(const int *device_ids, int n, pcr_group **out);
+PCR_API pcr_status pcr_group_destroy(pcr_group *g);
+PCR_API pcr_status pcr_group_size(pcr_group *g, int *n);
+PCR_API pcr_status pcr_group_context(pcr_group *g, int i, pcr_context **ctx);            /* borrowed */
+PCR_API pcr_status pcr_group_target_points_create(pcr_group *g, const float *xyz, int64_t n, const float *normals_or_null,
+                                                  float cell_hint, pcr_group_target **out);
+PCR_API pcr_status pcr_group_target_voxels_create(pcr_group *g, const void *xyz, int xyz_is_f64, int64_t n, double voxel_size,
+                                                  int min_points, pcr_group_target **out);
+PCR_API pcr_status pcr_group_target_estimate_normals(pcr_group_target *gt, int k, int compat, float *normals_out_or_null);
+PCR_API pcr_status pcr_group_target_set_normals(pcr_group_target *gt, const float *normals);
+PCR_API pcr_status pcr_group_target_points_set_f64(pcr_group_target *gt, const double *xyz64);
+PCR_API pcr_status pcr_group_target_member(pcr_group_target *gt, int i, pcr_target **t);  /* borrowed */
+PCR_API pcr_status pcr_group_target_destroy(pcr_group_target *gt);
+PCR_API pcr_status pcr_group_scan_create(pcr_group *g, const float *xyz, int64_t n, unsigned flags, pcr_group_scan **out);
+PCR_API pcr_status pcr_group_scan_size(pcr_group_scan *gs, int64_t *n);
+PCR_API pcr_status pcr_group_scan_destroy(pcr_group_scan *gs);
+PCR_API pcr_status pcr_group_linearize(pcr_group_target *gt, pcr_group_scan *gs, int kind, const double T[16], double max_dist,
+                                       unsigned flags, double out[29]);
+PCR_API pcr_status pcr_group_align(pcr_group_target *gt, pcr_group_scan *gs, int kind, const double T_init[16], int max_iter,
+                                   double tol, double max_dist, unsigned flags, double T_out[16], int *iterations,
+                                   double *trace_or_null);
 
 /* ---- targets ------------------------------------------------------------------------
  * pcr_target_points_create replaces ICP.set_target (icp.py:17-22) and the KD-tree half of

@@ -19,6 +19,7 @@ DEV_LIB_PATH = os.path.join(_HERE, "libpcr_hip_dev.so")
 
 PCR_OK = 0
 PCR_ERR_INVALID, PCR_ERR_HIP, PCR_ERR_NO_TARGET, PCR_ERR_COMM, PCR_ERR_SINGULAR, PCR_ERR_NOMEM = -1, -2, -3, -4, -5, -6
+PCR_ERR_UNSUPPORTED = -7
 ICP, PLANE, VPLANE, NDT = 0, 1, 2, 3
 FLAG_ICP_RR_QUIRK = 1
 FLAG_NO_SCAN_SORT = 2
@@ -32,6 +33,8 @@ NN_FULL, NN_TRACK, NN_LIST = 0, 1, 2      # what the search of a pass did (certi
 _lib = None
 _torch_lib_dir = None           # set when torch's bundled HIP runtime was pre-loaded (see below)
 _live = weakref.WeakSet()      # targets / scans still holding device memory
+_live_groups = weakref.WeakSet()   # pcr_groups (worker threads + member contexts)
+_groups = {}
 _shutdown = False
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
@@ -98,8 +101,27 @@ PROTOTYPES = {
     "pcr_context_trim": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "pcr_profile_read_n": (C.c_int, [_vp, C.c_int, _i64p, _f64p, C.POINTER(C.c_int)]),
     "pcr_scan_read_matches": (C.c_int, [_vp, _vp]),
+    "pcr_comm_p2p_finegrained": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    # single-process multi-device groups (include/pcr.h)
+    "pcr_group_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_vp)]),
+    "pcr_group_destroy": (C.c_int, [_vp]),
+    "pcr_group_size": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "pcr_group_context": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    "pcr_group_target_points_create": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_float, C.POINTER(_vp)]),
+    "pcr_group_target_voxels_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_double, C.c_int, C.POINTER(_vp)]),
+    "pcr_group_target_estimate_normals": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "pcr_group_target_set_normals": (C.c_int, [_vp, _f32p]),
+    "pcr_group_target_points_set_f64": (C.c_int, [_vp, _f64p]),
+    "pcr_group_target_member": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    "pcr_group_target_destroy": (C.c_int, [_vp]),
+    "pcr_group_scan_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_uint, C.POINTER(_vp)]),
+    "pcr_group_scan_size": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    "pcr_group_scan_destroy": (C.c_int, [_vp]),
+    "pcr_group_linearize": (C.c_int, [_vp, _vp, C.c_int, _f64p, C.c_double, C.c_uint, _f64p]),
+    "pcr_group_align": (C.c_int, [_vp, _vp, C.c_int, _f64p, C.c_int, C.c_double, C.c_double, C.c_uint, _f64p,
+                                  C.POINTER(C.c_int), _vp]),
 }
-ABI_VERSION = 4                 # PCR_ABI_VERSION of the include/pcr.h this binding was written against
+ABI_VERSION = 5                 # PCR_ABI_VERSION of the include/pcr.h this binding was written against
 
 
 class PcrError(RuntimeError):
@@ -307,6 +329,12 @@ class Context:
         check(lib().pcr_comm_p2p_attach(self.handle, blob, len(handles), int(rank)))
         self.nranks, self.rank = len(handles), int(rank)
 
+    def comm_p2p_finegrained(self):
+        """True: this rank's slots are fine-grained device memory (coherent across devices while a kernel runs)."""
+        f = C.c_int(0)
+        check(lib().pcr_comm_p2p_finegrained(self.handle, C.byref(f)))
+        return bool(f.value)
+
     def comm_p2p_failed(self):
         f = C.c_int(0)
         check(lib().pcr_comm_p2p_failed(self.handle, C.byref(f)))
@@ -339,7 +367,7 @@ class Context:
         return int(b.value)
 
     def close(self):
-        if getattr(self, "handle", None) and not _shutdown:
+        if getattr(self, "handle", None) and not _shutdown and not getattr(self, "_borrowed", False):
             lib().pcr_context_destroy(self.handle)
         self.handle = None
 
@@ -361,6 +389,12 @@ def _release_all():
         except Exception:
             pass
     _contexts.clear()
+    for grp in list(_groups.values()) + list(_live_groups):
+        try:
+            grp.close()
+        except Exception:
+            pass
+    _groups.clear()
     _shutdown = True
 
 
@@ -405,6 +439,10 @@ class Target:
             if normals.shape != xyz.shape:
                 raise ValueError("normals must have the shape of the target")
         h = _vp()
+        if isinstance(ctx, Group):
+            check(lib().pcr_group_target_points_create(ctx.handle, _ptr(xyz), xyz.shape[0], _ptr(normals),
+                                                       float(cell_hint), C.byref(h)))
+            return GroupTarget(ctx, h, False)
         check(lib().pcr_target_points_create(ctx.handle, _ptr(xyz), xyz.shape[0], _ptr(normals),
                                              float(cell_hint), C.byref(h)))
         return cls(ctx, h, False)
@@ -423,6 +461,10 @@ class Target:
         is64 = a.dtype == np.float64
         a = np.ascontiguousarray(a, dtype=np.float64 if is64 else np.float32)
         h = _vp()
+        if isinstance(ctx, Group):
+            check(lib().pcr_group_target_voxels_create(ctx.handle, _ptr(a), int(is64), a.shape[0], float(voxel_size),
+                                                       int(min_points), C.byref(h)))
+            return GroupTarget(ctx, h, True)
         check(lib().pcr_target_voxels_create(ctx.handle, _ptr(a), int(is64), a.shape[0], float(voxel_size),
                                              int(min_points), C.byref(h)))
         return cls(ctx, h, True)
@@ -448,8 +490,19 @@ class Target:
         xyz64 = np.ascontiguousarray(xyz64, dtype=np.float64)
         if xyz64.shape != (self.size(), 3):
             raise ValueError("xyz64 must have the shape of the target")
-        check(lib().pcr_target_points_set_f64(self.handle, xyz64))
+        fn = lib().pcr_group_target_points_set_f64 if getattr(self, "ghandle", None) else lib().pcr_target_points_set_f64
+        if not hasattr(fn, "argtypes"):          # (an older PCR_LIB without the entry point: its stub would "succeed")
+            return False
+        st = fn(getattr(self, "ghandle", None) or self.handle, xyz64)
+        if st == PCR_ERR_UNSUPPORTED:
+            # coordinates float32 cannot resolve (UTM-scale clouds): the float32 index stays, as before Q6 was reproduced
+            import warnings
+            warnings.warn("float64 target searched through its float32 copy: "
+                          + lib().pcr_last_error().decode("utf-8", "replace"), RuntimeWarning, stacklevel=3)
+            return False
+        check(st)
         self.has_f64 = True
+        return True
 
     def set_normals(self, normals):
         check(lib().pcr_target_set_normals(self.handle, np.ascontiguousarray(normals, dtype=np.float32)))
@@ -524,7 +577,18 @@ class Scan:
 
     def __init__(self, ctx, xyz=None, flags=0, device_ptr=None, n=None):
         self.ctx = ctx
+        self.ghandle = None
         h = _vp()
+        if isinstance(ctx, Group):
+            # a group scan: cut into one contiguous shard per member inside pcr_group_scan_create
+            xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+            if xyz.ndim != 2 or xyz.shape[1] != 3:
+                raise ValueError("scan must have shape (N, 3)")
+            check(lib().pcr_group_scan_create(ctx.handle, _ptr(xyz), xyz.shape[0], int(flags), C.byref(h)))
+            self.n = xyz.shape[0]
+            self.ghandle, self.handle = h, None
+            _live.add(self)
+            return
         if device_ptr is not None:
             check(lib().pcr_scan_create_device(ctx.handle, _vp(device_ptr), int(n), int(flags), C.byref(h)))
             self.n = int(n)
@@ -555,15 +619,86 @@ class Scan:
         return m
 
     def close(self):
-        if getattr(self, "handle", None) and not _shutdown:
+        if getattr(self, "ghandle", None) and not _shutdown:
+            lib().pcr_group_scan_destroy(self.ghandle)
+        elif getattr(self, "handle", None) and not _shutdown:
             lib().pcr_scan_destroy(self.handle)
         self.handle = None
+        self.ghandle = None
 
     def __del__(self):
         try:
             self.close()
         except Exception:
             pass
+
+
+class Group:
+    """pcr_group: single-process multi-device (include/pcr.h).  One context + host thread per entry of ``devices`` (an id
+    may repeat: ``[0, 0]`` = two contexts on one GPU).  Pass it wherever a Context is expected by ``Target.points`` /
+    ``Target.voxels`` / ``Scan``: targets are then built on every member, scans sharded contiguously, and ``linearize`` /
+    ``align`` return the sums / the pose over the WHOLE scan."""
+
+    def __init__(self, devices):
+        self.devices = tuple(int(d) for d in devices)
+        if not 1 <= len(self.devices) <= 8:
+            raise ValueError("a group has 1 to 8 member devices")
+        ids = (C.c_int * len(self.devices))(*self.devices)
+        h = _vp()
+        check(lib().pcr_group_create(ids, len(self.devices), C.byref(h)))
+        self.handle = h
+        self.nranks, self.rank = len(self.devices), 0
+        _live_groups.add(self)
+
+    def member(self, i):
+        """Member i's context (borrowed, not owned): profiling, pipeline switches, synchronize."""
+        h = _vp()
+        check(lib().pcr_group_context(self.handle, int(i), C.byref(h)))
+        c = Context.__new__(Context)
+        c.device, c.handle, c.nranks, c.rank, c._borrowed = self.devices[i], h, len(self.devices), int(i), True
+        return c
+
+    def synchronize(self):
+        for i in range(len(self.devices)):
+            self.member(i).synchronize()
+
+    def close(self):
+        if getattr(self, "handle", None) and not _shutdown:
+            lib().pcr_group_destroy(self.handle)
+        self.handle = None
+
+
+def get_group(devices):
+    """Process-wide group per device tuple (like get_context per device)."""
+    key = tuple(int(d) for d in devices)
+    if key not in _groups:
+        _groups[key] = Group(key)
+    return _groups[key]
+
+
+class GroupTarget(Target):
+    """pcr_group_target: the same target on every member.  ``handle`` is member 0's pcr_target (borrowed), so every
+    read-only method of Target (statistics, queries, index_info) answers from member 0; what changes the target runs on all."""
+
+    def __init__(self, group, ghandle, is_voxel):
+        self.ghandle = ghandle
+        h = _vp()
+        check(lib().pcr_group_target_member(ghandle, 0, C.byref(h)))
+        super().__init__(group, h, is_voxel)
+
+    def set_normals(self, normals):
+        check(lib().pcr_group_target_set_normals(self.ghandle, np.ascontiguousarray(normals, dtype=np.float32)))
+
+    def estimate_normals(self, k=15, compat=True, want=True):
+        out = np.empty((self.size(), 3), np.float32) if want else None
+        check(lib().pcr_group_target_estimate_normals(self.ghandle, int(k), int(bool(compat)), _ptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "ghandle", None) and not _shutdown:
+            lib().pcr_group_target_destroy(self.ghandle)
+        self.ghandle = None
+        self.handle = None
 
 
 def hash64(arr):
@@ -589,6 +724,11 @@ def linearize(target, scan, kind, T, max_dist, flags=FLAG_ICP_RR_QUIRK):
     out = np.empty(29)
     if not (isinstance(T, np.ndarray) and T.dtype == np.float64 and T.flags.c_contiguous and T.size == 16):
         T = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+    if getattr(target, "ghandle", None) is not None:              # a group: the sums over every member's shard
+        if getattr(scan, "ghandle", None) is None:
+            raise ValueError("a group target needs a scan created on the same group")
+        check(lib().pcr_group_linearize(target.ghandle, scan.ghandle, int(kind), T.reshape(16), float(max_dist), int(flags), out))
+        return out
     st = _linearize_fast(target.handle, scan.handle, kind, T.ctypes.data, max_dist, flags, out.ctypes.data)
     if st != PCR_OK:
         check(st)
@@ -601,8 +741,14 @@ def align(target, scan, kind, T_init, max_iter, tol, max_dist, flags=FLAG_ICP_RR
     T = np.zeros(16)
     iters = C.c_int(0)
     trace = np.zeros((max(int(max_iter), 1), 45)) if want_trace else None
-    check(lib().pcr_align(target.handle, scan.handle, int(kind), T0, int(max_iter), float(tol), float(max_dist),
-                          int(flags), T, C.byref(iters), _ptr(trace)))
+    if getattr(target, "ghandle", None) is not None:
+        if getattr(scan, "ghandle", None) is None:
+            raise ValueError("a group target needs a scan created on the same group")
+        check(lib().pcr_group_align(target.ghandle, scan.ghandle, int(kind), T0, int(max_iter), float(tol), float(max_dist),
+                                    int(flags), T, C.byref(iters), _ptr(trace)))
+    else:
+        check(lib().pcr_align(target.handle, scan.handle, int(kind), T0, int(max_iter), float(tol), float(max_dist),
+                              int(flags), T, C.byref(iters), _ptr(trace)))
     T = T.reshape(4, 4)
     if want_trace:
         return T, iters.value, trace[:iters.value]

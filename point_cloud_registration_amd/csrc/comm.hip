@@ -5,6 +5,7 @@
 // process that already imported PyTorch, resolves to the very same librccl.so.1 (one RCCL per
 // process).  232 bytes per message: latency-bound, xGMI bandwidth is irrelevant here.
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "pcr_internal.h"
@@ -97,8 +98,10 @@ struct P2PState {
     bool opened[PCR_P2P_MAXR] = {false};
     int nranks = 1, rank = 0;
     unsigned long long seq = 0;
-    int *d_err = nullptr;          // set by a rank that gave up waiting
+    int *h_err = nullptr;          // pinned + mapped: set by an exchange that gave up waiting (the host reads it without a copy)
+    int *d_err = nullptr;          // its device-side address
     bool finegrained = false;
+    bool local = false;            // peers live in THIS process (pcr_group): plain pointers, nothing to close
 };
 struct P2PArgs {
     double *peer[PCR_P2P_MAXR];
@@ -106,6 +109,7 @@ struct P2PArgs {
     unsigned long long seq;
     double *buf;
     int *err;
+    PoseDev *pose;                 // device-resident loop: a failed exchange ends it on this rank (PCR_LOOP_COMMFAIL)
 };
 
 __global__ void __launch_bounds__(64) k_p2p_allreduce(const P2PArgs p) {
@@ -132,7 +136,12 @@ __global__ void __launch_bounds__(64) k_p2p_allreduce(const P2PArgs p) {
         }
     }
     if (!__all(ok)) {
-        if (l == 0) __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (a late or dead peer must not read as PCR_OK.  The flag is what pcr_linearize / pcr_align check; the
+        // device-resident loop stops here, whatever the poisoned sums would have made k_gn_update do.)
+        if (l == 0) {
+            __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (p.pose && p.pose->done == PCR_LOOP_RUNNING) p.pose->done = PCR_LOOP_COMMFAIL;
+        }
         if (l < 29) p.buf[l] = __longlong_as_double(0x7ff8000000000000LL);      // the sums are NOT reduced: poison them
         return;
     }
@@ -145,36 +154,110 @@ __global__ void __launch_bounds__(64) k_p2p_allreduce(const P2PArgs p) {
     }
 }
 
+static void p2p_free(P2PState *st) {
+    if (!st) return;
+    if (!st->local) for (int r = 0; r < PCR_P2P_MAXR; ++r) if (st->opened[r]) (void)hipIpcCloseMemHandle(st->peer[r]);
+    if (st->own) (void)hipFree(st->own);
+    if (st->h_err) (void)hipHostFree(st->h_err);
+    delete st;
+}
+
+// the slots of one rank + its error word.  fine-grained memory: peers' system-scope stores become visible to this GPU's
+// loads without a kernel boundary; *handle (optional): the IPC handle of the block
+static pcr_status p2p_state_create(pcr_context *ctx, hipIpcMemHandle_t *handle, P2PState **out) {
+    P2PState *st = new P2PState();
+    hipError_t e = hipExtMallocWithFlags((void **)&st->own, PCR_P2P_BYTES, hipDeviceMallocFinegrained);
+    st->finegrained = e == hipSuccess;
+    if (e != hipSuccess) { (void)hipGetLastError(); st->own = nullptr; e = hipMalloc((void **)&st->own, PCR_P2P_BYTES); }
+    if (e != hipSuccess) { st->own = nullptr; p2p_free(st); pcr_set_error("p2p slots: %s", hipGetErrorString(e)); return PCR_ERR_HIP; }
+    if (handle) {
+        e = hipIpcGetMemHandle(handle, st->own);
+        if (e != hipSuccess && st->finegrained) {                    // (some runtimes export coarse-grained blocks only)
+            (void)hipGetLastError(); (void)hipFree(st->own); st->own = nullptr; st->finegrained = false;
+            e = hipMalloc((void **)&st->own, PCR_P2P_BYTES);
+            if (e != hipSuccess) st->own = nullptr;
+            else e = hipIpcGetMemHandle(handle, st->own);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            p2p_free(st);
+            pcr_set_error("hipIpcGetMemHandle: %s", hipGetErrorString(e));
+            return PCR_ERR_COMM;
+        }
+    }
+    // (coarse-grained memory is not coherent ACROSS devices while a kernel runs -- a spin on it may never see the
+    // peer's flag.  Ranks that share one device go through its one L2 with system-scope accesses, which is the case the
+    // fallback exists for (two processes on the test box); PCR_P2P_ALLOW_COARSE=0 refuses it, and pcr_comm_p2p_finegrained
+    // lets the ranks agree before anybody exchanges: distributed.py takes the host transport when ranks on DIFFERENT devices
+    // could not get fine-grained slots.)
+    if (!st->finegrained) {
+        const char *ac = getenv("PCR_P2P_ALLOW_COARSE");
+        if (ac && atoi(ac) == 0) { p2p_free(st); pcr_set_error("p2p slots: no fine-grained device memory"); return PCR_ERR_COMM; }
+    }
+    hipError_t e2 = hipMemset(st->own, 0, PCR_P2P_BYTES);
+    if (e2 == hipSuccess) e2 = hipHostMalloc((void **)&st->h_err, sizeof(int) * 16, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e2 == hipSuccess) { st->h_err[0] = 0; e2 = hipHostGetDevicePointer((void **)&st->d_err, st->h_err, 0); }
+    if (e2 != hipSuccess) { (void)hipGetLastError(); p2p_free(st); pcr_set_error("p2p state: %s", hipGetErrorString(e2)); return PCR_ERR_HIP; }
+    *out = st;
+    return PCR_OK;
+}
+
 extern "C" pcr_status pcr_comm_p2p_export(pcr_context *ctx, void *handle64) {
     PCR_REQUIRE(ctx && handle64, "NULL argument");
     PCR_REQUIRE(!ctx->comm, "communicator already initialised");
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "the boundary hands IPC handles around as 64 bytes");
     HIP_TRY(hipSetDevice(ctx->device));
-    P2PState *st = new P2PState();
-    // fine-grained memory: peers' system-scope stores become visible to this GPU's loads without a kernel boundary
-    hipError_t e = hipExtMallocWithFlags((void **)&st->own, PCR_P2P_BYTES, hipDeviceMallocFinegrained);
-    st->finegrained = e == hipSuccess;
-    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc((void **)&st->own, PCR_P2P_BYTES); }
-    if (e != hipSuccess) { delete st; pcr_set_error("p2p slots: %s", hipGetErrorString(e)); return PCR_ERR_HIP; }
     hipIpcMemHandle_t h;
-    e = hipIpcGetMemHandle(&h, st->own);
-    if (e != hipSuccess && st->finegrained) {                    // (some runtimes export coarse-grained blocks only)
-        (void)hipGetLastError(); (void)hipFree(st->own); st->own = nullptr; st->finegrained = false;
-        e = hipMalloc((void **)&st->own, PCR_P2P_BYTES);
-        if (e == hipSuccess) e = hipIpcGetMemHandle(&h, st->own);
-    }
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        if (st->own) (void)hipFree(st->own);
-        delete st;
-        pcr_set_error("hipIpcGetMemHandle: %s", hipGetErrorString(e));
-        return PCR_ERR_COMM;
-    }
-    HIP_TRY(hipMemset(st->own, 0, PCR_P2P_BYTES));
-    HIP_TRY(hipMalloc((void **)&st->d_err, sizeof(int)));
-    HIP_TRY(hipMemset(st->d_err, 0, sizeof(int)));
+    P2PState *st = nullptr;
+    PCR_TRY(p2p_state_create(ctx, &h, &st));
     memcpy(handle64, &h, 64);
     ctx->comm = st; ctx->comm_kind = 1; ctx->nranks = 1; ctx->rank = 0;
+    return PCR_OK;
+}
+
+// 1 when this context's slots are fine-grained (coherent across devices inside a kernel), 0 for the coarse-grained fallback
+extern "C" pcr_status pcr_comm_p2p_finegrained(pcr_context *ctx, int *finegrained) {
+    PCR_REQUIRE(ctx && finegrained, "NULL argument");
+    *finegrained = (ctx->comm && ctx->comm_kind == 1 && ((P2PState *)ctx->comm)->finegrained) ? 1 : 0;
+    return PCR_OK;
+}
+
+// ---- the same transport between contexts of ONE process (pcr_group, group.hip): peers are plain pointers ---------------
+pcr_status pcr_comm_p2p_local(pcr_context *const *members, int n) {
+    PCR_REQUIRE(members && n >= 1 && n <= PCR_P2P_MAXR, "a group has 1 to 8 members");
+    if (n == 1) return PCR_OK;
+    for (int i = 0; i < n; ++i) {
+        pcr_context *ctx = members[i];
+        PCR_REQUIRE(ctx && !ctx->comm, "member context already has a communicator");
+        HIP_TRY(hipSetDevice(ctx->device));
+        for (int j = 0; j < n; ++j) {
+            if (members[j]->device == ctx->device) continue;
+            const hipError_t e = hipDeviceEnablePeerAccess(members[j]->device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                pcr_set_error("hipDeviceEnablePeerAccess(%d -> %d): %s", ctx->device, members[j]->device, hipGetErrorString(e));
+                (void)hipGetLastError();
+                return PCR_ERR_COMM;
+            }
+            (void)hipGetLastError();
+        }
+        P2PState *st = nullptr;
+        PCR_TRY(p2p_state_create(ctx, nullptr, &st));
+        st->local = true;
+        bool other_device = false;
+        for (int j = 0; j < n; ++j) other_device |= members[j]->device != ctx->device;
+        if (!st->finegrained && other_device) {
+            p2p_free(st);
+            pcr_set_error("peer-to-peer slots across devices need fine-grained device memory");
+            return PCR_ERR_COMM;
+        }
+        ctx->comm = st; ctx->comm_kind = 1;
+    }
+    for (int i = 0; i < n; ++i) {
+        P2PState *st = (P2PState *)members[i]->comm;
+        for (int r = 0; r < n; ++r) st->peer[r] = ((P2PState *)members[r]->comm)->own;
+        st->nranks = n; st->rank = i;
+        members[i]->nranks = n; members[i]->rank = i;
+    }
     return PCR_OK;
 }
 
@@ -194,6 +277,7 @@ extern "C" pcr_status pcr_comm_p2p_attach(pcr_context *ctx, const void *handles,
         st->peer[r] = (double *)p; st->opened[r] = true;
     }
     st->nranks = nranks; st->rank = rank;
+    st->h_err[0] = 0;
     ctx->nranks = nranks; ctx->rank = rank;
     return PCR_OK;
 }
@@ -202,11 +286,7 @@ extern "C" pcr_status pcr_comm_destroy(pcr_context *ctx) {
     if (!ctx || !ctx->comm) return PCR_OK;
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm_kind == 1) {
-        P2PState *st = (P2PState *)ctx->comm;
-        for (int r = 0; r < PCR_P2P_MAXR; ++r) if (st->opened[r]) (void)hipIpcCloseMemHandle(st->peer[r]);
-        if (st->own) (void)hipFree(st->own);
-        if (st->d_err) (void)hipFree(st->d_err);
-        delete st;
+        p2p_free((P2PState *)ctx->comm);
     } else if (g_nccl.CommDestroy) {
         (void)g_nccl.CommDestroy((nccl_comm_t)ctx->comm);
     }
@@ -221,16 +301,22 @@ extern "C" pcr_status pcr_comm_p2p_failed(pcr_context *ctx, int *failed) {
     if (!ctx->comm || ctx->comm_kind != 1) return PCR_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipMemcpy(failed, ((P2PState *)ctx->comm)->d_err, sizeof(int), hipMemcpyDeviceToHost));
+    *failed = __atomic_load_n(((P2PState *)ctx->comm)->h_err, __ATOMIC_ACQUIRE) != 0 ? 1 : 0;
     return PCR_OK;
 }
 
-pcr_status pcr_comm_allreduce29(pcr_context *ctx, double *d_buf) {
+// the same word without a synchronisation: what pcr_linearize / pcr_align look at once the exchange they wait for is over
+bool pcr_comm_failed_now(pcr_context *ctx) {
+    if (!ctx->comm || ctx->comm_kind != 1) return false;
+    return __atomic_load_n(((P2PState *)ctx->comm)->h_err, __ATOMIC_ACQUIRE) != 0;
+}
+
+pcr_status pcr_comm_allreduce29(pcr_context *ctx, double *d_buf, PoseDev *pose) {
     if (ctx->comm_kind == 1) {
         P2PState *st = (P2PState *)ctx->comm;
         P2PArgs a;
         for (int r = 0; r < PCR_P2P_MAXR; ++r) a.peer[r] = st->peer[r];
-        a.n = st->nranks; a.rank = st->rank; a.seq = ++st->seq; a.buf = d_buf; a.err = st->d_err;
+        a.n = st->nranks; a.rank = st->rank; a.seq = ++st->seq; a.buf = d_buf; a.err = st->d_err; a.pose = pose;
         hipLaunchKernelGGL(k_p2p_allreduce, dim3(1), dim3(64), 0, ctx->stream, a);
         HIP_TRY(hipGetLastError());
         return PCR_OK;

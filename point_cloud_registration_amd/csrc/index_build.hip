@@ -895,9 +895,12 @@ pcr_status pcr_attach_points_f64(pcr_context *ctx, pcr_target *t, const double *
     memcpy(&band, &bits, 8);
     const Geom<float> &gf = t->gf;
     if (!(band <= 0.25 * (double)gf.h)) {
-        pcr_set_error("the float64 coordinates are not those of the target's float32 points (a point moves by %g m, cell %g m)",
-                      band, (double)gf.h);
-        return PCR_ERR_INVALID;
+        // (not an argument error.  Coordinates of UTM magnitude have a float32 ulp of 0.03-0.5 m: rounding moves the
+        // points by more than the float32 index can bound with a usable band.  The target keeps its float32 index -- the
+        // caller may go on with the float32 search, as the previous revision did -- and says so.)
+        pcr_set_error("float64 search coordinates not attached: rounding to float32 moves a point by %g m (cell %g m); "
+                      "the target keeps its float32 search", band, (double)gf.h);
+        return PCR_ERR_UNSUPPORTED;
     }
     pcr_persist_free(ctx, t->pts64);
     t->pts64 = out.release();

@@ -169,7 +169,7 @@ __device__ __forceinline__ void nn_chunk_loop(const LinArgs &a, Body &&body) {
 #define PCR_VOX_WAVES 4
 #endif
 template <int VOXEL, int HALO, int LOCAL, int MODE, int RB = 0>
-__global__ void __launch_bounds__(256, VOXEL == 2 ? PCR_VOX_WAVES : 5) k_nn_scan(const LinArgs a) {
+__global__ void __launch_bounds__(256, VOXEL == 2 ? PCR_VOX_WAVES : (RB ? 4 : 5)) k_nn_scan(const LinArgs a) {
     PoseK P;
     PoseQ Q;
     if (!load_pose<false>(a, P)) return;
@@ -350,9 +350,13 @@ __device__ __forceinline__ void gn_update(const FinArgs &f, double (*A)[7]) {
 // the step of the device-resident loop: a 1-wave launch behind the fold (single GPU) or behind the
 // all-reduce of the 29 sums (multi-GPU: every rank computes the same update)
 __global__ void __launch_bounds__(64) k_gn_update(const FinArgs f) {
-    if (threadIdx.x == 0 && f.pose->done == PCR_LOOP_RUNNING) {
+    if (threadIdx.x != 0) return;
+    if (f.pose->done == PCR_LOOP_RUNNING) {
         double A[6][7];                 // registers: gn_solve6 indexes it with compile-time constants only
         gn_update(f, A);
+    } else if (f.pose->done == PCR_LOOP_COMMFAIL && f.host_state) {
+        // the exchange in front of this launch gave up waiting for a peer: tell the host, which is watching this word
+        *f.host_state = ((unsigned long long)(unsigned)PCR_LOOP_COMMFAIL << 32) | (unsigned)f.pose->iter;
     }
 }
 
@@ -612,8 +616,12 @@ bool pcr_pass_is_fused(const pcr_context *ctx, const pcr_scan *s) {
 }
 
 static void set_filter_bound(LinArgs &a, double bound);
+// (bits 27-29 of LinArgs::flags are internal -- the gate switch of quirk Q6, two developer timing switches; a
+// caller-supplied word must not reach them)
+#define PCR_PUBLIC_FLAGS (PCR_FLAG_ICP_RR_QUIRK | PCR_FLAG_NO_SCAN_SORT | PCR_FLAG_LOCAL_ONLY | PCR_FLAG_HOST_LOOP | PCR_FLAG_DEVICE_LOOP)
 static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, double max_dist, unsigned flags) {
     pcr_context *ctx = t->ctx;
+    flags &= PCR_PUBLIC_FLAGS;
     PCR_REQUIRE(s->ctx == ctx, "scan and target belong to different contexts");
     PCR_REQUIRE(kind >= PCR_ICP && kind <= PCR_NDT, "unknown kind");
     PCR_REQUIRE(max_dist > 0, "max_dist must be positive");
@@ -721,7 +729,7 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
     const double bound = max_dist * (1.0 + 1e-6);
     a.bound2_f = (float)(bound * bound); a.bound2_d = bound * bound;
     set_filter_bound(a, bound);
-    a.flags = flags;
+    a.flags = flags;           // (public bits were masked by the callers below: PCR_PUBLIC_FLAGS; internal bits are OR-ed in above)
     a.nblocks = choose_blocks(ctx, s->n);
     a.partials = ctx->d_partials;
     a.nn_j = s->nn_j; a.tile_ctr = ctx->d_tile_ctr + 9 * PCR_TICKET_STRIDE;
@@ -1032,6 +1040,10 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
     }
     if (flagged) {
         PCR_TRY(wait_host_word(ctx, [&] { return *flag == seq; }, "finalize kernel"));
+        if (use_comm && pcr_comm_failed_now(ctx)) {
+            pcr_set_error("peer-to-peer exchange: a peer did not arrive (its sums were not reduced)");
+            return PCR_ERR_COMM;
+        }
         if (stall_dbg) {                     // developer (PCR_STALL_DEBUG): where did a slow call spend its time?
             clock_gettime(CLOCK_MONOTONIC, &ts2); clock_gettime(CLOCK_THREAD_CPUTIME_ID, &tc2);
             const double cpu = (tc2.tv_sec - tc0.tv_sec) * 1e3 + (tc2.tv_nsec - tc0.tv_nsec) * 1e-6;
@@ -1052,6 +1064,10 @@ pcr_status pcr_run_linearize(pcr_target *t, pcr_scan *s, int kind, const double 
     }
     HIP_TRY(hipMemcpyAsync(ctx->h_out, ctx->d_out, sizeof(double) * 31, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (use_comm && pcr_comm_failed_now(ctx)) {
+        pcr_set_error("peer-to-peer exchange: a peer did not arrive (its sums were not reduced)");
+        return PCR_ERR_COMM;
+    }
     for (int i = 0; i < 29; ++i) out[i] = ctx->h_out[i];
     if (mode == PCR_NN_LIST && !use_comm) {
         s->last_marked = (int64_t)ctx->h_out[29];
@@ -1117,7 +1133,7 @@ pcr_status pcr_run_align(pcr_target *t, pcr_scan *s, int kind, const double T_in
         if (use_comm) {
             ProfEvent ev;
             pcr_prof_begin(ctx, PCR_K_ALLREDUCE, &ev);
-            pcr_status cs = pcr_comm_allreduce29(ctx, ctx->d_out);
+            pcr_status cs = pcr_comm_allreduce29(ctx, ctx->d_out, ctx->d_pose);
             pcr_prof_end(ctx, &ev);
             if (cs != PCR_OK) return cs;
         }
@@ -1145,6 +1161,13 @@ pcr_status pcr_run_align(pcr_target *t, pcr_scan *s, int kind, const double T_in
             spin = 0;
         }
     }
+    if (use_comm && loop_done() == PCR_LOOP_COMMFAIL) {
+        //  this rank's exchange timed out: no top-up -- the peers are gone or late, and whatever they do with
+        // their own timeouts, this call must not report a pose
+        (void)hipStreamSynchronize(ctx->stream);
+        pcr_set_error("peer-to-peer exchange: a peer did not arrive after %d iteration(s)", passes_done());
+        return PCR_ERR_COMM;
+    }
     if (use_comm) {
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         const int it_end = passes_done();
@@ -1159,6 +1182,10 @@ pcr_status pcr_run_align(pcr_target *t, pcr_scan *s, int kind, const double T_in
     if (trace_or_null && it > 0) {
         HIP_TRY(hipMemcpyAsync(trace_or_null, ctx->d_trace, sizeof(double) * 45 * (size_t)it, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    if (use_comm && pcr_comm_failed_now(ctx)) {
+        pcr_set_error("peer-to-peer exchange: a peer did not arrive");
+        return PCR_ERR_COMM;
     }
     if (done == PCR_LOOP_SINGULAR) {
         pcr_set_error("Singular matrix");

@@ -380,14 +380,18 @@ __device__ __forceinline__ void nn_rings_box(const Geom<float> &g, const PtF *__
     const float qs2 = qs * qs;
     const float mq = g.slack * qs + 1.5f;
     const float ux0 = (qx - g.ox) * qs, uy0 = (qy - g.oy) * qs, uz0 = (qz - g.oz) * qs;
-    // one segment [xl, xh] of row (y, z), cells at `row`; rrow = its first box record
-    auto segment = [&](uint32_t row, uint32_t rrow, float uy, float uz, int xl, int xh) __attribute__((always_inline)) {
+    // Variant B (the one kept in the tree; variant A -- commit 55c01ec -- read the box FIRST and clipped the segment to the
+    // block's occupied cells and to the ball's reach: a third dependent load per row, slower at every pose): the box records
+    // of a shell row's segment [xl, xh] are requested TOGETHER with its two cell_start words, and the segment's candidates are
+    // skipped when every non-empty block it touches lies beyond the current best.  Returns true when the segment must be read.
+    auto box_hit = [&](uint32_t rrow, float uy, float uz, int xl, int xh) __attribute__((always_inline)) -> bool {
+        bool hit = false;
+        const float pbq = best * qs2;
         for (int xb = xl >> PCR_RB_LOG; xb <= (xh >> PCR_RB_LOG); ++xb) {
             const uint2 w = g.rbox[rrow + (uint32_t)xb];
             const int x0 = xb << PCR_RB_LOG;
             const int lo = max(xl - x0, 0), hi = min(xh - x0, (1 << PCR_RB_LOG) - 1);
-            uint32_t m = (w.x & 0xffu) & (0xffu << lo) & (0xffu >> (7 - hi));
-            if (m == 0) { if (STATS) st->rows_pruned++; continue; }
+            const uint32_t m = (w.x & 0xffu) & (0xffu << lo) & (0xffu >> (7 - hi));
             const float ux = ux0 - (float)x0 * 256.f;                            // the query from the block's corner, y / z steps
             const float xlo = (float)((w.x >> 8) & 0xffu) * 8.f, xhi = (float)((w.x >> 16) & 0xffu) * 8.f + 8.f;
             const float ylo = (float)(w.x >> 24), yhi = (float)(w.y & 0xffu) + 1.f;
@@ -395,21 +399,9 @@ __device__ __forceinline__ void nn_rings_box(const Geom<float> &g, const PtF *__
             const float dx = fmaxf(fmaxf(xlo - ux, ux - xhi) - mq, 0.f);
             const float dy = fmaxf(fmaxf(ylo - uy, uy - yhi) - mq, 0.f);
             const float dz = fmaxf(fmaxf(zlo - uz, uz - zhi) - mq, 0.f);
-            const float dyz = dy * dy + dz * dz;
-            const float pbq = best * qs2;
-            if (dyz + dx * dx > pbq) { if (STATS) st->rows_pruned++; continue; }
-            if (pbq < RT::inf()) {                          // what the ball leaves of the box's (y, z) distance, in cells of this block
-                const float xr = RT::sqrt_fast(pbq - dyz) * 1.000002f + mq;
-                const float a = (ux - xr) * (1.f / 256.f), b = (ux + xr) * (1.f / 256.f);
-                const int la = a > 0.f ? (int)fminf(a, 8.f) : 0, hb = b < 8.f ? (b < 0.f ? -1 : (int)b) : 7;
-                m &= (0xffu << la) & (hb >= 0 ? (0xffu >> (7 - hb)) : 0u);
-                if (m == 0) { if (STATS) st->rows_pruned++; continue; }
-            }
-            const int l2 = __builtin_ctz(m), h2 = 31 - __builtin_clz(m);
-            const uint32_t s_ = cs[row + (uint32_t)(x0 + l2)] & g.cs_mask, e_ = cs[row + (uint32_t)(x0 + h2) + 1u] & g.cs_mask;
-            if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-            nn_scan_range<float, PtF, 0, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, nullptr);
+            hit |= (m != 0) & !((dy * dy + dz * dz) + dx * dx > pbq);
         }
+        return hit;
     };
     for (int k = kstart; k <= c.kmax; ++k) {
         if (nn_certified<float>(g, c, k, best)) break;
@@ -437,7 +429,6 @@ __device__ __forceinline__ void nn_rings_box(const Geom<float> &g, const PtF *__
                 dym = fmaxf(dym - g.slack, 0.f);
                 const float dyz2 = dz2 + dym * dym;
                 if (dyz2 > best) { if (STATS) st->rows_pruned++; continue; }
-                const float uy = uy0 - (float)y * 256.f;
                 if (zshell || dyc == k || dyc == -k) {
                     int xl = xlo, xh = xhi;
                     if (best < RT::inf()) {                 // clip the row to the remaining budget (cube bound; the box clips again)
@@ -446,10 +437,25 @@ __device__ __forceinline__ void nn_rings_box(const Geom<float> &g, const PtF *__
                         if (a > (float)xl) xl = (int)RT::floor_(fminf(a, lim));
                         if (b < (float)xh) xh = (int)RT::floor_(fmaxf(b, -lim));
                     }
-                    if (xl <= xh) segment(row, rrow, uy, uz, xl, xh);
-                } else {                                    // interior row of the ring: its two end cells
-                    if (xa_in && dyz2 + dxa <= best) segment(row, rrow, uy, uz, xa, xa);
-                    if (xb_in && dyz2 + dxb <= best) segment(row, rrow, uy, uz, xb, xb);
+                    if (xl <= xh) {
+                        const uint32_t s_ = cs[row + (uint32_t)xl] & g.cs_mask, e_ = cs[row + (uint32_t)xh + 1u] & g.cs_mask;
+                        const bool hit = box_hit(rrow, uy0 - (float)y * 256.f, uz, xl, xh);
+                        if (hit) {
+                            if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
+                            nn_scan_range<float, PtF, 0, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, nullptr);
+                        } else if (STATS) st->rows_pruned++;
+                    }
+                } else {                                    // interior row of the ring: its two end cells (single cells: no box test)
+                    if (xa_in && dyz2 + dxa <= best) {
+                        const uint32_t s_ = cs[row + (uint32_t)xa] & g.cs_mask, e_ = cs[row + (uint32_t)xa + 1u] & g.cs_mask;
+                        if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
+                        nn_scan_range<float, PtF, 0, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, nullptr);
+                    }
+                    if (xb_in && dyz2 + dxb <= best) {
+                        const uint32_t s_ = cs[row + (uint32_t)xb] & g.cs_mask, e_ = cs[row + (uint32_t)xb + 1u] & g.cs_mask;
+                        if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
+                        nn_scan_range<float, PtF, 0, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, nullptr);
+                    }
                 }
             }
         }

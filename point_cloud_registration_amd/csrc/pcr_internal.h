@@ -110,6 +110,7 @@ struct PoseDev {
 #define PCR_LOOP_CONVERGED 1
 #define PCR_LOOP_SINGULAR 2
 #define PCR_LOOP_MAXITER 3
+#define PCR_LOOP_COMMFAIL 4   // an exchange of this rank gave up waiting for a peer (comm.hip: k_p2p_allreduce)
 
 // ---- temporaries: a per-context cache of device blocks ------------------------------------------
 // hipFree synchronises the device and costs ~60 us; a target / scan / voxel build used to issue 10-40 of
@@ -392,4 +393,6 @@ void pcr_prof_begin(pcr_context *ctx, int kernel, ProfEvent *ev);
 void pcr_prof_end(pcr_context *ctx, ProfEvent *ev);
 
 // ---- comm.cpp
-pcr_status pcr_comm_allreduce29(pcr_context *ctx, double *d_buf);
+pcr_status pcr_comm_allreduce29(pcr_context *ctx, double *d_buf, PoseDev *pose = nullptr);
+bool pcr_comm_failed_now(pcr_context *ctx);                       // a peer-to-peer exchange of this context timed out
+pcr_status pcr_comm_p2p_local(pcr_context *const *members, int n);   // in-process peers (pcr_group)

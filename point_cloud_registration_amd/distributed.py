@@ -48,8 +48,18 @@ class Communicator:
             except Exception as exc:
                 ok = 0
                 print(f"[pcr] rank {self.rank}: peer-to-peer export failed ({exc})", flush=True)
-            handles = [None] * self.world
-            dist.all_gather_object(handles, handle, group=group)
+            #  coarse-grained slots -- the fallback of pcr_comm_p2p_export -- are coherent only between ranks that
+            # share ONE device; ranks on different devices that could not get fine-grained slots take the host transport
+            import socket
+            me = (handle, bool(ok and ctx.comm_p2p_finegrained()), (socket.gethostname(), int(ctx.device)))
+            infos = [None] * self.world
+            dist.all_gather_object(infos, me, group=group)
+            handles = [i[0] for i in infos]
+            if not all(i[1] for i in infos) and len({i[2] for i in infos}) > 1:
+                ok = 0
+                if self.rank == 0:
+                    print("[pcr] peer-to-peer slots are not fine-grained on every rank and the ranks span several devices: "
+                          "host all-reduce instead", flush=True)
             if ok and all(h is not None for h in handles):
                 try:
                     ctx.comm_p2p_attach(handles, self.rank)

@@ -11,6 +11,10 @@ Additions (none changes a default):
 * ``device=`` -- which GPU this process drives (default ``LOCAL_RANK``);
 * ``comm=`` -- a :class:`distributed.Communicator`; the scan passed to ``align`` is then this
   rank's SHARD and every ``calc_H_g_e2`` returns the sum over all ranks (SURVEY.md section 8e);
+* ``devices=`` -- a list of GPU ids for ONE process (``PlaneICP(devices=[0, 1, 2, 3, 4, 5, 6, 7])``): ``set_target`` builds
+  the target on every listed GPU, ``align`` / ``calc_H_g_e2`` take the WHOLE scan, shard it across them behind the C ABI
+  (``pcr_group_*``) and exchange the 29 sums GPU to GPU -- the reference's single-process call order
+  (registration.py:28,71; demo_matching.py:147-152) on a whole node, no torchrun (SURVEY.md sections 5 and 8b);
 * ``upload(source)`` -- returns a handle to the device copy of a scan; ``calc_H_g_e2(cur_T, handle)`` and
   ``align(handle)`` then skip the upload and the per-call content hash of the array form;
 * ``native_loop`` (default True) -- ``align`` runs the whole loop behind the C ABI (``pcr_align``):
@@ -42,12 +46,15 @@ class Registration:
     KIND = None           # _capi.ICP / PLANE / VPLANE / NDT in the subclasses
 
     def __init__(self, max_iter=30, tol=1e-3, device=None, comm=None, native_loop=True,
-                 compat_flags=_capi.FLAG_ICP_RR_QUIRK):
+                 compat_flags=_capi.FLAG_ICP_RR_QUIRK, devices=None):
         self.max_iter = max_iter
         self.tol = tol
         self._is_target_set = False
         self._device = device
         self._comm = comm
+        if devices is not None and (comm is not None or device is not None):
+            raise ValueError("devices= (one process, several GPUs) excludes device= and comm= (one process per GPU)")
+        self._group = _capi.get_group(devices) if devices is not None else None
         self._native_loop = native_loop
         self._flags = compat_flags
         self._target = None            # _capi.Target
@@ -114,6 +121,8 @@ class Registration:
 
     # -- internals -----------------------------------------------------------------------------
     def _ctx(self):
+        if self._group is not None:
+            return self._group
         if self._comm is not None and getattr(self._comm, "ctx", None) is not None:
             return self._comm.ctx
         return _capi.get_context(self._device)
@@ -127,7 +136,7 @@ class Registration:
     def _call_flags(self):
         """The collective is a per-call decision: only a Registration that was given ``comm=`` joins the
         all-reduce, whatever else shares the (process-wide) context."""
-        if self._comm is not None and self._comm.in_library:
+        if self._group is not None or (self._comm is not None and self._comm.in_library):
             return self._flags
         return self._flags | _capi.FLAG_LOCAL_ONLY
 
