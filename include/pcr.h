@@ -273,6 +273,12 @@ PCR_API pcr_status pcr_profile_read(pcr_context *ctx, int64_t launches[PCR_K_COU
 PCR_API pcr_status pcr_profile_read_n(pcr_context *ctx, int capacity, int64_t *launches, double *total_ms, int *count);
 /* grid geometry of a target's NN index: cell size, dims, occupied cells, points (or voxels) */
 PCR_API pcr_status pcr_target_index_info(pcr_target *t, double *cell, int64_t dims[3], int64_t *occupied, int64_t *n);
+/* How unevenly the points fill the index (round 6): the largest and the 99th-percentile population of an OCCUPIED cell, and
+ * whether the target was built as "heavy" (some cells hold far more points than the average -- a LiDAR sweep's ring lines,
+ * density ~ 1/r^2): its cell edge then stops at PCR_CELLS_PER_POINT (default 8) grid cells per point instead of shrinking to
+ * ~5 points per occupied cell, the points of a cell are Morton-sorted, and every range of more than 24 records is searched
+ * through boxes over 64 and 8 consecutive records (csrc/nn_device.h: nn_scan_range_lb).  Any pointer may be NULL.         */
+PCR_API pcr_status pcr_target_index_population(pcr_target *t, int64_t *pop_max, int64_t *pop_p99, int *heavy);
 /* point targets: margin (metres) and total records of the extended per-cell lists ring 0 searches (a cell's
  * own points plus the neighbours' points within the margin of the shared face; PCR_HALO sets the margin as a
  * fraction of the cell edge, default 0.1, 0 = none).  Voxel targets: the same of the float32 filter index over

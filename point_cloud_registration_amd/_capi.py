@@ -83,6 +83,7 @@ PROTOTYPES = {
     "pcr_profile_read": (C.c_int, [_vp, _i64p, _f64p]),
     "pcr_target_index_info": (C.c_int, [_vp, C.POINTER(C.c_double), _i64p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pcr_target_index_halo": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "pcr_target_index_population": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "pcr_set_variant": (C.c_int, [_vp, C.c_int]),
     "pcr_get_variant": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "pcr_set_nn_mode": (C.c_int, [_vp, C.c_int]),
@@ -536,9 +537,12 @@ class Target:
         check(lib().pcr_target_filter_band(self.handle, C.byref(band)))
         halo2, nh2 = C.c_double(0), C.c_int64(0)
         check(lib().pcr_target_index_halo2(self.handle, C.byref(halo2), C.byref(nh2)))
+        pmax, p99, heavy = C.c_int64(0), C.c_int64(0), C.c_int(0)
+        check(lib().pcr_target_index_population(self.handle, C.byref(pmax), C.byref(p99), C.byref(heavy)))
         return {"cell": cell.value, "dims": tuple(int(d) for d in dims), "occupied": occ.value, "n": n.value,
                 "halo": halo.value, "halo_records": nh.value, "filter_band": band.value,
-                "halo2": halo2.value, "halo2_records": nh2.value}
+                "halo2": halo2.value, "halo2_records": nh2.value,
+                "pop_max": pmax.value, "pop_p99": p99.value, "heavy": bool(heavy.value)}
 
     def nn_query(self, q, r_max=np.inf):
         q = np.ascontiguousarray(q, dtype=np.float32)

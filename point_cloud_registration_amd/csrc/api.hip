@@ -452,7 +452,7 @@ static void target_free(pcr_target *t) { pcr_target_release(t); }
 void pcr_target_release(pcr_target *t) {
     if (!t) return;
     target_free(t->filter);
-    void *ptrs[] = {t->cell_start, t->cell_seed, t->rowocc, t->rbox, t->cs_h, t->pts_h, t->j_h, t->cs_h2, t->pts_h2, t->j_h2, t->pts, t->pn, t->pts64, t->means, t->vnorm, t->vicov,
+    void *ptrs[] = {t->cell_start, t->cell_seed, t->rowocc, t->rbox, t->lbox, t->gbox, t->lbox_h, t->gbox_h, t->lbox_h2, t->gbox_h2, t->cs_h, t->pts_h, t->j_h, t->cs_h2, t->pts_h2, t->j_h2, t->pts, t->pn, t->pts64, t->means, t->vnorm, t->vicov,
                     t->st_mean, t->st_cov, t->st_norm, t->st_icov, t->st_counts, t->st_keys};
     if (t->ctx) (void)hipSetDevice(t->ctx->device);
     for (void *p : ptrs) pcr_persist_free(t->ctx, p);
@@ -630,6 +630,19 @@ extern "C" pcr_status pcr_target_index_info(pcr_target *t, double *cell, int64_t
     }
     if (occupied) *occupied = t->occupied;
     if (n) *n = t->n;
+    return PCR_OK;
+}
+
+extern "C" pcr_status pcr_target_index_population(pcr_target *t, int64_t *pop_max, int64_t *pop_p99, int *heavy) {
+    PCR_REQUIRE(t, "NULL argument");
+    if (pop_max || pop_p99) {
+        HIP_TRY(hipSetDevice(t->ctx->device));
+        CtxScope scope(t->ctx);
+        PCR_TRY(pcr_cell_population(t->ctx, t));
+    }
+    if (pop_max) *pop_max = t->pop_max;
+    if (pop_p99) *pop_p99 = t->pop_p99;
+    if (heavy) *heavy = t->heavy ? 1 : 0;
     return PCR_OK;
 }
 

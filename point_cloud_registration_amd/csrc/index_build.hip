@@ -168,24 +168,59 @@ static unsigned long long occ_total(const unsigned long long *h) {
 
 // (occ: += the number of cells this launch touched first, i.e. the occupied cells of a histogram that started at zero -- one
 // atomic per block; a separate counting pass over the cells cost as much as this kernel, round 5)
+// Position of a point inside its cell as a Morton code of 3 x `b` bits (b <= 3): the minor sort key of a target with heavy
+// cells, so that 8 / 64 consecutive records of a cell are a compact patch (leaf / group boxes, Geom::lbox)
+template <typename Real>
+__device__ __forceinline__ uint32_t sub_morton(const Geom<Real> &g, Real x, Real y, Real z, int b) {
+    const Real s = (Real)(1 << b);
+    const Real ux = (x - g.ox) * g.inv_h, uy = (y - g.oy) * g.inv_h, uz = (z - g.oz) * g.inv_h;
+    const int m = (1 << b) - 1;
+    const int ix = min(max((int)((ux - floor(ux)) * s), 0), m), iy = min(max((int)((uy - floor(uy)) * s), 0), m),
+              iz = min(max((int)((uz - floor(uz)) * s), 0), m);
+    uint32_t code = 0;
+    for (int k = 0; k < b; ++k)
+        code |= (((uint32_t)ix >> k) & 1u) << (3 * k) | (((uint32_t)iy >> k) & 1u) << (3 * k + 1) | (((uint32_t)iz >> k) & 1u) << (3 * k + 2);
+    return code;
+}
+
+// (occ: += the number of cells this launch touched first, i.e. the occupied cells of a histogram that started at zero -- one
+// atomic per block; a separate counting pass over the cells cost as much as this kernel, round 5)
+// sub_bits > 0: cell_id = (cell << sub_bits) | Morton code of the position inside the cell.
+// occ[slot + 1] (histogram passes): max over the block of the population its points saw their cells reach (round 6: the probe
+// of the automatic cell size also tells whether some cells are far heavier than the average)
 template <typename Real, typename T>
 __global__ void __launch_bounds__(256) k_cell_ids(const T *__restrict__ xyz, int64_t n, Geom<Real> g,
-                                                  uint32_t *cell_id, uint32_t *idx, uint32_t *counts, unsigned long long *occ) {
-    __shared__ unsigned firsts;
-    if (threadIdx.x == 0) firsts = 0;
+                                                  uint32_t *cell_id, uint32_t *idx, uint32_t *counts, unsigned long long *occ,
+                                                  int sub_bits) {
+    __shared__ unsigned firsts, popmax;
+    if (threadIdx.x == 0) { firsts = 0; popmax = 0; }
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     bool first = false;
+    unsigned pop = 0;
     if (i < n) {
-        const uint32_t c = cell_of<Real>(g, (Real)xyz[3 * i], (Real)xyz[3 * i + 1], (Real)xyz[3 * i + 2]);
-        if (cell_id) { cell_id[i] = c; idx[i] = (uint32_t)i; }
-        if (counts) first = atomicAdd(&counts[c], 1u) == 0u;
+        const Real x = (Real)xyz[3 * i], y = (Real)xyz[3 * i + 1], z = (Real)xyz[3 * i + 2];
+        const uint32_t c = cell_of<Real>(g, x, y, z);
+        if (cell_id) {
+            cell_id[i] = sub_bits > 0 ? (c << sub_bits) | sub_morton<Real>(g, x, y, z, sub_bits / 3) : c;
+            idx[i] = (uint32_t)i;
+        }
+        if (counts) { pop = atomicAdd(&counts[c], 1u) + 1u; first = pop == 1u; }
     }
     if (!counts) return;                 // (ids only: block-uniform)
     const unsigned long long m = __ballot(first);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&firsts, (unsigned)__popcll(m));
+    for (int off = 32; off >= 1; off >>= 1) pop = max(pop, (unsigned)__shfl_xor((int)pop, off, 64));
+    if ((threadIdx.x & 63) == 0) { if (m) atomicAdd(&firsts, (unsigned)__popcll(m)); atomicMax(&popmax, pop); }
     __syncthreads();
-    if (threadIdx.x == 0 && firsts) atomicAdd(&occ[(blockIdx.x % OCC_SLOTS) * OCC_STRIDE], (unsigned long long)firsts);
+    if (threadIdx.x == 0) {
+        if (firsts) atomicAdd(&occ[(blockIdx.x % OCC_SLOTS) * OCC_STRIDE], (unsigned long long)firsts);
+        atomicMax(&occ[(blockIdx.x % OCC_SLOTS) * OCC_STRIDE + 1], (unsigned long long)popmax);
+    }
+}
+static unsigned long long occ_popmax(const unsigned long long *h) {
+    unsigned long long t = 0;
+    for (int i = 0; i < OCC_SLOTS; ++i) t = h[i * OCC_STRIDE + 1] > t ? h[i * OCC_STRIDE + 1] : t;
+    return t;
 }
 
 // cell_start from the SORTED cell ids instead of an atomic histogram (the final pass' 1.06 M atomics on random cells took 58 us,
@@ -193,15 +228,15 @@ __global__ void __launch_bounds__(256) k_cell_ids(const T *__restrict__ xyz, int
 // a reverse running minimum then gives every cell -- the empty ones included -- the position of the first record at or behind
 // it, which IS the exclusive prefix of the counts.  occ += the occupied cells.
 __global__ void __launch_bounds__(256) k_cell_heads(const uint32_t *__restrict__ cid, int64_t n, int64_t ncells, uint32_t *head,
-                                                    unsigned long long *occ) {
+                                                    unsigned long long *occ, int shift) {
     __shared__ unsigned firsts;
     if (threadIdx.x == 0) firsts = 0;
     __syncthreads();
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     bool first = false;
     if (j < n) {
-        const uint32_t c = cid[j];
-        first = j == 0 || cid[j - 1] != c;
+        const uint32_t c = cid[j] >> shift;               // (shift: the sub-cell bits of a heavy target's sort key)
+        first = j == 0 || (cid[j - 1] >> shift) != c;
         if (first) head[c] = (uint32_t)j;
         if (j == 0) head[ncells] = (uint32_t)n;
     }
@@ -421,7 +456,7 @@ static bool make_geom(const float lo[3], const float hi[3], double h, Geom<Real>
     g->slack = (Real)(16.0 * eps * (mag + h) + 1e-30);
     g->cs_mask = 0xffffffffu;
     g->seed = nullptr;
-    g->halo = (Real)0; g->cs_h = nullptr; g->pts_h = nullptr; g->j_h = nullptr; g->rowocc = nullptr; g->nyw = 0; g->nxb = 0; g->rbox = nullptr; g->nxr = 0;
+    g->halo = (Real)0; g->cs_h = nullptr; g->pts_h = nullptr; g->j_h = nullptr; g->rowocc = nullptr; g->nyw = 0; g->nxb = 0; g->rbox = nullptr; g->nxr = 0; g->lbox = nullptr; g->gbox = nullptr; g->lbox_h = nullptr; g->gbox_h = nullptr;
     return true;
 }
 
@@ -508,7 +543,9 @@ static pcr_status build_halo_lists(pcr_context *ctx, Geom<float> gh, const PtF *
 template <typename Real, typename T, typename PT>
 static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double h, bool auto_h, Geom<Real> *geom,
                              uint32_t **cell_start_out, uint32_t **seed_out, PT **pts_out, int64_t *occupied_out,
-                             double halo_frac, uint32_t **cs_h_out, PtF **pts_h_out, uint32_t **j_h_out, int64_t *n_h_out) {
+                             double halo_frac, uint32_t **cs_h_out, PtF **pts_h_out, uint32_t **j_h_out, int64_t *n_h_out,
+                             bool *heavy_out = nullptr) {
+    if (heavy_out) *heavy_out = false;
     *seed_out = nullptr;
     *cs_h_out = nullptr; *pts_h_out = nullptr; *j_h_out = nullptr; *n_h_out = 0;
     PCR_REQUIRE(n < ((int64_t)1 << 31), "at most 2^31-1 points per target");
@@ -536,6 +573,21 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
     const unsigned nb = (unsigned)((n + 255) / 256);
     int dir = 0;                  // auto cell size moves in one direction only: -1 shrinking, +1 growing
     bool capped = false;          // hit the memory cap: cannot shrink further
+    // Round 6: the automatic cell never shrinks below the edge at which the dense grid would hold more than PCR_CELLS_PER_POINT
+    // (default 8) cells per point.  "~5 points per occupied cell" is the right target for a cloud of constant density; on a
+    // LiDAR sweep (ring lines, density ~ 1/r^2: synthetic.lidar_sweep) it drives the edge to 6 cm -- 7e8 cells for 1e6 points, and a
+    // query one metre from its match walks 17 rings of them (22.9 ms for a pass that takes 0.22 ms on the street cloud).  Such
+    // clouds keep cells of the sparse regime and their heavy cells are searched through leaf / group boxes instead (Geom::lbox).
+    double h_floor = 0.0;
+    unsigned long long pop_max = 0;
+    bool probed = false;
+    if (auto_h && n > 0) {
+        static const double cpp = getenv("PCR_CELLS_PER_POINT") && atof(getenv("PCR_CELLS_PER_POINT")) > 0 ? atof(getenv("PCR_CELLS_PER_POINT")) : 8.0;
+        double vol = 1.0;
+        for (int a = 0; a < 3; ++a) vol *= fmax((double)hi[a] - (double)lo[a], 0.0);
+        h_floor = cbrt(vol / (cpp * (double)n));
+        if (!std::isfinite(h_floor)) h_floor = 0.0;
+    }
     // (a given cell size needs no probing pass: the final histogram below counts its occupied cells)
     for (int iter = 0; iter < 16 && auto_h && n > 0; ++iter) {
         Geom<Real> g;
@@ -547,12 +599,17 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
         HIP_TRY(hipMemsetAsync(d_counts.p, 0, sizeof(uint32_t) * ((size_t)ncells + 1), ctx->stream));
         HIP_TRY(hipMemsetAsync(d_nz.p, 0, sizeof(unsigned long long) * OCC_WORDS, ctx->stream));
         hipLaunchKernelGGL((k_cell_ids<Real, T>), dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, g,
-                           (uint32_t *)nullptr, (uint32_t *)nullptr, d_counts.p, d_nz.p);
+                           (uint32_t *)nullptr, (uint32_t *)nullptr, d_counts.p, d_nz.p, 0);
         HIP_TRY(hipMemcpyAsync(h_nz.data(), d_nz.p, sizeof(unsigned long long) * OCC_WORDS, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         occupied = (int64_t)occ_total(h_nz.data());
+        pop_max = occ_popmax(h_nz.data());
+        probed = true;
         const double occ = (double)n / (double)(occupied > 0 ? occupied : 1);
-        if (occ > 10.0 && dir <= 0 && !capped) { h *= 0.5; dir = -1; continue; }
+        if (occ > 10.0 && dir <= 0 && !capped) {
+            if (h * 0.5 >= h_floor) { h *= 0.5; dir = -1; continue; }
+            if (h > h_floor * 1.05) { h = h_floor; dir = -1; continue; }      // one last probe AT the floor
+        }
         if (occ < 2.5 && dir >= 0) { h *= 2.0; dir = 1; continue; }
         break;
     }
@@ -562,7 +619,16 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
         const double occ = (double)n / (double)occupied;
         double f = sqrt(5.0 / occ);
         f = f < 0.70710678 ? 0.70710678 : (f > 1.41421356 ? 1.41421356 : f);
-        h *= f;
+        h = fmax(h * f, fmin(h, h_floor));
+    }
+    // heavy cells?  (the probe's largest cell against its average cell; a given cell size has no probe: assume so.  Only the
+    // float32 point index has the boxes; sort keys stay 32 bits wide)
+    const double occ_mean = (double)n / (double)(occupied > 0 ? occupied : 1);
+    bool heavy = heavy_out != nullptr && sizeof(Real) == 4 && n >= 4096 &&
+                 (!probed || ((double)pop_max > 64.0 && (double)pop_max > 12.0 * occ_mean));
+    {
+        const char *he = getenv("PCR_HEAVY");                 // developer: 0 never, 1 always
+        if (he && *he && heavy_out != nullptr && sizeof(Real) == 4 && n > 0) heavy = atoi(he) != 0;
     }
     // with the final h: ids + fresh histogram
     Geom<Real> g;
@@ -582,11 +648,16 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
     // sentinel records behind the last point (see nn_scan_range): +inf coordinates, index ~0
     hipLaunchKernelGGL(k_pad_sentinels<PT>, dim3(1), dim3(64), 0, ctx->stream, d_pts.p + (size_t)n);
     HIP_TRY(hipMemsetAsync(d_nz.p, 0, sizeof(unsigned long long) * OCC_WORDS, ctx->stream));
+    int sub_bits = 0;
+    if (heavy) {                  // minor sort key: Morton code of the position inside the cell, as many bits as 32-bit keys leave
+        sub_bits = 32 - bits_for(ncells);
+        sub_bits = sub_bits >= 9 ? 9 : (sub_bits / 3) * 3;
+    }
     if (n > 0) {
         hipLaunchKernelGGL((k_cell_ids<Real, T>), dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, g, d_cid.p, d_idx.p,
-                           (uint32_t *)nullptr, (unsigned long long *)nullptr);
-        PCR_TRY(sort_pairs<uint32_t>(ctx, d_cid, d_cid2, d_idx, d_idx2, n, bits_for(ncells)));
-        hipLaunchKernelGGL(k_cell_heads, dim3(nb), dim3(256), 0, ctx->stream, (const uint32_t *)d_cid2.p, n, (int64_t)ncells, d_counts.p, d_nz.p);
+                           (uint32_t *)nullptr, (unsigned long long *)nullptr, sub_bits);
+        PCR_TRY(sort_pairs<uint32_t>(ctx, d_cid, d_cid2, d_idx, d_idx2, n, bits_for(ncells) + sub_bits));
+        hipLaunchKernelGGL(k_cell_heads, dim3(nb), dim3(256), 0, ctx->stream, (const uint32_t *)d_cid2.p, n, (int64_t)ncells, d_counts.p, d_nz.p, sub_bits);
         if (sizeof(Real) == 4)
             hipLaunchKernelGGL(k_gather_f32, dim3(nb), dim3(256), 0, ctx->stream, (const float *)d_xyz,
                                (const uint32_t *)d_idx2.p, n, (PtF *)d_pts.p);
@@ -604,6 +675,7 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
     const bool nz2_pending = n > 0;
     // ---- halo lists (point targets with a gap field: both share the 28-bit offsets)
     g.halo = (Real)0; g.cs_h = nullptr; g.pts_h = nullptr; g.j_h = nullptr; g.rowocc = nullptr; g.nyw = 0; g.nxb = 0; g.rbox = nullptr; g.nxr = 0;
+    g.lbox = nullptr; g.gbox = nullptr; g.lbox_h = nullptr; g.gbox_h = nullptr;
     DevBuf<uint32_t> d_cs_h, d_j_h;
     DevBuf<PtF> d_pts_h;
     int64_t n_h = 0;
@@ -626,6 +698,7 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
     *j_h_out = d_j_h.release();
     *seed_out = d_seed.release();
     *occupied_out = occupied;
+    if (heavy_out) *heavy_out = heavy;
     *cell_start_out = d_counts.release();
     *pts_out = d_pts.release();
     return PCR_OK;
@@ -660,6 +733,90 @@ static pcr_status make_row_occ(pcr_context *ctx, const uint32_t *cs, Geom<Real> 
     HIP_TRY(hipGetLastError());
     *out = buf.release();             // (not synchronised: pcr_voxel_target_finish does, once, behind the permutations)
     g->rowocc = *out;
+    return PCR_OK;
+}
+
+// leaf / group boxes (Geom::lbox, gbox): min / max corner of every 8 and of every 64 consecutive records of a point array
+// (its sentinel records excluded).  One thread per leaf; the 8 leaves of a group sit in 8 neighbouring lanes.
+__global__ void __launch_bounds__(256) k_leaf_boxes(const PtF *__restrict__ pts, int64_t n, float4 *__restrict__ lbox, float4 *__restrict__ gbox) {
+    const int64_t L = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t nleaf = (n + 7) >> 3;
+    const float inf = __builtin_inff();
+    float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+    if (L < nleaf) {
+        const int64_t j1 = min((L << 3) + 8, n);
+        for (int64_t j = L << 3; j < j1; ++j) {
+            const PtF p = pts[j];
+            lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
+            lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
+            lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
+        }
+        lbox[2 * L] = make_float4(lo[0], lo[1], lo[2], 0.f);
+        lbox[2 * L + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+    }
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, 64));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
+        }
+    }
+    if ((threadIdx.x & 7) == 0 && L < nleaf) {
+        gbox[2 * (L >> 3)] = make_float4(lo[0], lo[1], lo[2], 0.f);
+        gbox[2 * (L >> 3) + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+    }
+}
+
+// boxes over `n` records (+ a few leaves of padding so that a scan that over-reads a batch into the sentinels finds a box)
+static pcr_status make_leaf_boxes(pcr_context *ctx, const PtF *pts, int64_t n, float4 **lbox_out, float4 **gbox_out) {
+    *lbox_out = nullptr; *gbox_out = nullptr;
+    if (n <= 0) return PCR_OK;
+    const int64_t nleaf = (n + 7) >> 3, ngroup = (nleaf + 7) >> 3;
+    DevBuf<float4> lb, gb;
+    HIP_TRY(lb.alloc_exact((size_t)(2 * nleaf + 8)));
+    HIP_TRY(gb.alloc_exact((size_t)(2 * ngroup + 8)));
+    hipLaunchKernelGGL(k_leaf_boxes, dim3((unsigned)((nleaf + 255) / 256)), dim3(256), 0, ctx->stream, pts, n, lb.p, gb.p);
+    HIP_TRY(hipGetLastError());
+    *lbox_out = lb.release(); *gbox_out = gb.release();
+    return PCR_OK;
+}
+
+// population of the occupied cells: counts of cells by population (exact up to 1023, then one bin per power of two) + the maximum
+__global__ void __launch_bounds__(256) k_cell_pop(const uint32_t *__restrict__ cs, uint32_t mask, int64_t ncells, unsigned long long *hist,
+                                                  unsigned long long *pmax) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncells) return;
+    const uint32_t pop = (cs[c + 1] & mask) - (cs[c] & mask);
+    if (pop == 0) return;
+    const int bin = pop < 1024u ? (int)pop : 1024 + (31 - __builtin_clz(pop));
+    atomicAdd(&hist[bin], 1ull);
+    atomicMax(pmax, (unsigned long long)pop);
+}
+
+pcr_status pcr_cell_population(pcr_context *ctx, pcr_target *t) {
+    if (t->pop_max > 0 || t->n <= 0) return PCR_OK;
+    const int64_t ncells = t->is_voxel ? (int64_t)t->gd.nx * t->gd.ny * t->gd.nz : (int64_t)t->gf.nx * t->gf.ny * t->gf.nz;
+    const uint32_t mask = t->is_voxel ? t->gd.cs_mask : t->gf.cs_mask;
+    DevBuf<unsigned long long> d;
+    const int bins = 1024 + 32 + 1;
+    HIP_TRY(d.alloc((size_t)bins));
+    HIP_TRY(hipMemsetAsync(d.p, 0, sizeof(unsigned long long) * bins, ctx->stream));
+    hipLaunchKernelGGL(k_cell_pop, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t *)t->cell_start, mask,
+                       ncells, d.p, d.p + (bins - 1));
+    HIP_TRY(hipGetLastError());
+    std::vector<unsigned long long> h((size_t)bins);
+    HIP_TRY(hipMemcpyAsync(h.data(), d.p, sizeof(unsigned long long) * bins, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    t->pop_max = (int64_t)h[(size_t)bins - 1];
+    unsigned long long total = 0, run = 0;
+    for (int b = 0; b < bins - 1; ++b) total += h[(size_t)b];
+    t->pop_p99 = t->pop_max;
+    for (int b = 0; b < bins - 1; ++b) {
+        run += h[(size_t)b];
+        if ((double)run >= 0.99 * (double)total) { t->pop_p99 = b < 1024 ? b : (int64_t)1 << (b - 1024 + 1); break; }   // (upper edge of a log bin)
+    }
+    if (t->pop_p99 > t->pop_max) t->pop_p99 = t->pop_max;
     return PCR_OK;
 }
 
@@ -739,11 +896,23 @@ pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n,
     double halo = n <= ((int64_t)1 << 24) ? halo_default : 0.0;
     const char *he = getenv("PCR_HALO");
     if (he && *he) halo = atof(he);
+    bool heavy = false;
     PCR_TRY((build_grid<float, float, PtF>(ctx, d_xyz, n, h, auto_h, &t->gf, &t->cell_start, &t->cell_seed, &t->pts, &t->occupied,
-                                           halo, &t->cs_h, &t->pts_h, &t->j_h, &t->n_h)));
-    // row-block boxes for the far search (round 6; PCR_RBOX=0: none -> the plain ring loop)
+                                           halo, &t->cs_h, &t->pts_h, &t->j_h, &t->n_h, use_env ? &heavy : nullptr)));
+    t->heavy = heavy;
+    if (heavy) {                  // leaf / group boxes over the cell-sorted points and over the extended lists
+        PCR_TRY(make_leaf_boxes(ctx, t->pts, n, &t->lbox, &t->gbox));
+        t->gf.lbox = t->lbox; t->gf.gbox = t->gbox;
+        if (t->pts_h) {
+            PCR_TRY(make_leaf_boxes(ctx, t->pts_h, t->n_h, &t->lbox_h, &t->gbox_h));
+            t->gf.lbox_h = t->lbox_h; t->gf.gbox_h = t->gbox_h;
+        }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    // row-block boxes for the far search (round 6): measured SLOWER than the plain ring loop in both forms that were built
+    // (docs/EXPERIMENTS.md, profiles/r06_rowbox_null.txt: -6 % L1 accesses for +27 % VALU instructions) -- opt-in, PCR_RBOX=1
     const char *re = use_env ? getenv("PCR_RBOX") : nullptr;
-    if (use_env && !(re && atoi(re) == 0)) PCR_TRY(make_row_boxes(ctx, t));      // (use_env = false: the filter index of a voxel target)
+    if (use_env && !heavy && re && atoi(re) == 1) PCR_TRY(make_row_boxes(ctx, t));      // (use_env = false: the filter index of a voxel target)
     return PCR_OK;       // (no row-occupancy bitmap for point targets: measured slower, nn_device.h)
 }
 
@@ -773,6 +942,10 @@ pcr_status pcr_build_deep_lists(pcr_context *ctx, pcr_target *t) {
     t->halo2 = (float)(PCR_HALO2_FRAC * (double)t->gf.h);
     t->n_h2 = n_h;
     t->cs_h2 = cs_h.release(); t->pts_h2 = pts_h.release(); t->j_h2 = j_h.release();
+    if (t->heavy) {
+        PCR_TRY(make_leaf_boxes(ctx, t->pts_h2, n_h, &t->lbox_h2, &t->gbox_h2));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
     return PCR_OK;
 }
 
@@ -914,6 +1087,7 @@ pcr_status pcr_attach_points_f64(pcr_context *ctx, pcr_target *t, const double *
     g.slack = (double)gf.slack * 2.0 + t->band64;
     g.cs_mask = gf.cs_mask;
     g.seed = nullptr; g.halo = 0; g.cs_h = nullptr; g.pts_h = nullptr; g.j_h = nullptr; g.rowocc = nullptr; g.nyw = 0; g.nxb = 0; g.rbox = nullptr; g.nxr = 0;
+    g.lbox = nullptr; g.gbox = nullptr; g.lbox_h = nullptr; g.gbox_h = nullptr;
     return PCR_OK;
 }
 

@@ -169,7 +169,7 @@ __device__ __forceinline__ void nn_chunk_loop(const LinArgs &a, Body &&body) {
 #define PCR_VOX_WAVES 4
 #endif
 template <int VOXEL, int HALO, int LOCAL, int MODE, int RB = 0>
-__global__ void __launch_bounds__(256, VOXEL == 2 ? PCR_VOX_WAVES : (RB ? 4 : 5)) k_nn_scan(const LinArgs a) {
+__global__ void __launch_bounds__(256, VOXEL == 2 ? PCR_VOX_WAVES : (RB ? 4 : 5)) k_nn_scan(const LinArgs a) {       // RB: see nn_point
     PoseK P;
     PoseQ Q;
     if (!load_pose<false>(a, P)) return;
@@ -286,9 +286,12 @@ template <int VOXEL, int MODE>
 static void launch_nn_scan_mode(bool halo, int local, dim3 grid, hipStream_t st, const LinArgs &a) {
     const dim3 block(256);
     // (RB: plain full searches of a point target that carries row-block boxes, Geom::rbox)
+    // (LB: a target with heavy cells, Geom::lbox -- it carries no row-block boxes)
     constexpr bool can_rb = VOXEL == 0 && MODE == PCR_NN_FULL;
-    const bool rb = can_rb && a.gf.rbox != nullptr;
-#define PCR_NN_CASE(H, L) do { if (rb) hipLaunchKernelGGL((k_nn_scan<VOXEL, (VOXEL ? 0 : H), L, MODE, can_rb ? 1 : 0>), grid, block, 0, st, a); \
+    const bool lb = can_rb && a.gf.lbox != nullptr;
+    const bool rb = can_rb && !lb && a.gf.rbox != nullptr;
+#define PCR_NN_CASE(H, L) do { if (lb) hipLaunchKernelGGL((k_nn_scan<VOXEL, (VOXEL ? 0 : H), L, MODE, can_rb ? 2 : 0>), grid, block, 0, st, a); \
+                               else if (rb) hipLaunchKernelGGL((k_nn_scan<VOXEL, (VOXEL ? 0 : H), L, MODE, can_rb ? 1 : 0>), grid, block, 0, st, a); \
                                else hipLaunchKernelGGL((k_nn_scan<VOXEL, (VOXEL ? 0 : H), L, MODE, 0>), grid, block, 0, st, a); } while (0)
     if (MODE == PCR_NN_FULL && local == 2) { if (halo) PCR_NN_CASE(1, 2); else PCR_NN_CASE(0, 2); return; }
     if (halo) { if (local) PCR_NN_CASE(1, 1); else PCR_NN_CASE(1, 0); }
@@ -472,14 +475,14 @@ __global__ void __launch_bounds__(256, FIX ? 4 : 1) k_reduce_finalize(const LinA
 // tile per wave at 129-191 VGPRs anyway, so -- unlike in the streaming reduce kernel -- the step's registers cost no
 // occupancy, and the iteration saves the k_gn_update launch (~8 us of a 46 us iteration on a 100 k-point scan).  Every
 // other block read the pose before it contributed its ticket, so rewriting it here races with nothing.
-template <int KIND, int HALO, int GN, int FILT>
+template <int KIND, int HALO, int GN, int FILT, int LB = 0>
 __global__ void __launch_bounds__(256) k_linearize_finalize(const LinArgs a, const FinArgs f) {
     PoseK P;
     if (!load_pose<true>(a, P)) return;
     double acc[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = 0.0;
-    linearize_body<KIND, HALO, FILT>(a, P, acc);
+    linearize_body<KIND, HALO, FILT, LB>(a, P, acc);
     const bool last = ticket_fold_emit(acc, a, f);
     if (GN && last && threadIdx.x == 0 && f.pose->done == PCR_LOOP_RUNNING) {
         double A[6][7];
@@ -497,14 +500,14 @@ __global__ void __launch_bounds__(64) k_publish(const double *__restrict__ out, 
 }
 
 // ---- fine seam: plain NN queries (no transform), original indices out -------------------------
-template <typename Real, typename PT, bool HALO>
+template <typename Real, typename PT, bool HALO, bool LB = false>
 __global__ void __launch_bounds__(256) k_nn_query(Geom<Real> g, const PT *pts, const uint32_t *cs,
                                                   const float *q, int64_t m, Real bound2, Real rmax,
                                                   Real *dist, int64_t *idx) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= m) return;
     Real best; uint32_t bj, bo;
-    nn_search<Real, PT, false, false, HALO>(g, pts, cs, (Real)q[3 * i], (Real)q[3 * i + 1], (Real)q[3 * i + 2], bound2, best, bj, bo);
+    nn_search<Real, PT, false, false, HALO, 0, false, PCR_NN_BATCH, false, LB>(g, pts, cs, (Real)q[3 * i], (Real)q[3 * i + 1], (Real)q[3 * i + 2], bound2, best, bj, bo);
     bj = bo;                                       // (only tested against PCR_NONE below)
     Real d = RealTraits<Real>::sqrt_rn(best);
     if (bj != PCR_NONE && rmax < RealTraits<Real>::inf() && !(d < rmax)) bj = PCR_NONE;
@@ -562,6 +565,8 @@ pcr_status pcr_ensure_scratch(pcr_context *ctx, int64_t n_points) {
             int nb = 0;
             const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<0, 1, 0, 0, 1>, 256, 0);
             ctx->nn_blocks_rb = (e == hipSuccess && nb > 0) ? nb : 4;
+            const hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<0, 1, 0, 0, 2>, 256, 0);
+            ctx->nn_blocks_lb = (e2 == hipSuccess && nb > 0) ? nb : 4;
         }
         for (int v = 0; v < 4; ++v) {
             int nb = 0;
@@ -723,7 +728,7 @@ static pcr_status pass_setup(Pass *ps, pcr_target *t, pcr_scan *s, int kind, dou
             t->deep_tried = true;
             if (pcr_build_deep_lists(ctx, t) != PCR_OK) (void)hipGetLastError();
         }
-        if (t->cs_h2) { a.cs_h2 = t->cs_h2; a.pts_h2 = t->pts_h2; a.j_h2 = t->j_h2; a.halo2_f = t->halo2; }
+        if (t->cs_h2) { a.cs_h2 = t->cs_h2; a.pts_h2 = t->pts_h2; a.j_h2 = t->j_h2; a.halo2_f = t->halo2; a.lbox_h2 = t->lbox_h2; a.gbox_h2 = t->gbox_h2; }
     }
     a.md_f = (float)max_dist; a.md_d = max_dist;
     const double bound = max_dist * (1.0 + 1e-6);
@@ -841,7 +846,10 @@ static pcr_status pass_enqueue(Pass *ps) {
         // rounded centroids (HALO then refers to the FILTER index)
         const bool filt = ps->t->is_voxel && a.band_f > 0.f && ps->fused_fin;
         const bool halo = ps->t->is_voxel ? (filt && ps->t->filter->cs_h != nullptr) : ps->t->cs_h != nullptr;
-#define PCR_LIN_LAUNCH(K, H, G, F) hipLaunchKernelGGL((k_linearize_finalize<K, H, G, F>), grid, block, 0, ctx->stream, a, ps->f)
+        const bool lbf = !ps->t->is_voxel && a.gf.lbox != nullptr;      // heavy point target: ranges through their leaf / group boxes
+#define PCR_LIN_LAUNCH(K, H, G, F) do { if constexpr ((K) == PCR_ICP || (K) == PCR_PLANE) { \
+            if (lbf) { hipLaunchKernelGGL((k_linearize_finalize<K, H, G, F, 1>), grid, block, 0, ctx->stream, a, ps->f); break; } } \
+        hipLaunchKernelGGL((k_linearize_finalize<K, H, G, F, 0>), grid, block, 0, ctx->stream, a, ps->f); } while (0)
 #define PCR_LIN_CASE_F(K, F)                                                      \
         if (ps->gn_inline) { if (halo) PCR_LIN_LAUNCH(K, 1, 1, F); else PCR_LIN_LAUNCH(K, 0, 1, F); }  \
         else { if (halo) PCR_LIN_LAUNCH(K, 1, 0, F); else PCR_LIN_LAUNCH(K, 0, 0, F); }
@@ -879,7 +887,10 @@ static pcr_status pass_enqueue(Pass *ps) {
         {   // exactly one resident generation of waves; they share the tiles dynamically
             RoctxRange range("pcr:nn_search");
             int64_t nb = (int64_t)ctx->num_cu * ctx->nn_blocks_per_cu[filter ? 3 : vox ? 1 : (ctx->nn_mode == 2 && !ps->q6 ? 2 : 0)];
-            if (!filter && !vox && mode == PCR_NN_FULL && a.gf.rbox != nullptr && ctx->nn_mode != 2) nb = (int64_t)ctx->num_cu * ctx->nn_blocks_rb;
+            if (!filter && !vox && mode == PCR_NN_FULL && ctx->nn_mode != 2) {
+                if (a.gf.lbox != nullptr) nb = (int64_t)ctx->num_cu * ctx->nn_blocks_lb;
+                else if (a.gf.rbox != nullptr) nb = (int64_t)ctx->num_cu * ctx->nn_blocks_rb;
+            }
             // tiles of the hand-out: 64 points per wave, or the 1024-point chunks of a LIST pass (one block per chunk)
             const int64_t tiles = mode == PCR_NN_LIST ? (a.n + PCR_LIST_CHUNK - 1) / PCR_LIST_CHUNK : (a.n + 63) / 64;
             const int64_t need = mode == PCR_NN_LIST ? tiles : (tiles + 3) / 4;
@@ -922,6 +933,7 @@ static pcr_status pass_enqueue(Pass *ps) {
                 // host-driven pass: the list set by how far the scan moved since the previous pass (unknown: the deeper one)
                 if (a.pose == nullptr && a.halo2_f > 0.f && mode == PCR_NN_FULL && !(ps->motion >= 0.0 && ps->motion < ps->f.deep_len)) {
                     ps->a.gf.halo = a.halo2_f; ps->a.gf.cs_h = a.cs_h2; ps->a.gf.pts_h = a.pts_h2; ps->a.gf.j_h = a.j_h2;
+                    ps->a.gf.lbox_h = a.lbox_h2; ps->a.gf.gbox_h = a.gbox_h2;
                 }
                 launch_nn_scan<0>(mode, ps->t->cs_h != nullptr, ps->a.sched_local, nn_grid, ctx->stream, a);
             } else if (filter) {
@@ -1207,7 +1219,13 @@ pcr_status pcr_run_nn(pcr_target *t, const float *d_q, int64_t m, double r_max, 
         const float inf = __builtin_inff();
         const double b = r_max * (1.0 + 1e-6);
         const float bound2 = bounded ? (float)(b * b) : inf;
-        if (t->cs_h)
+        if (t->gf.lbox && t->cs_h)
+            hipLaunchKernelGGL((k_nn_query<float, PtF, true, true>), grid, block, 0, ctx->stream, t->gf, t->pts, t->cell_start, d_q, m,
+                               bound2, bounded ? (float)r_max : inf, (float *)d_dist, d_idx);
+        else if (t->gf.lbox)
+            hipLaunchKernelGGL((k_nn_query<float, PtF, false, true>), grid, block, 0, ctx->stream, t->gf, t->pts, t->cell_start, d_q, m,
+                               bound2, bounded ? (float)r_max : inf, (float *)d_dist, d_idx);
+        else if (t->cs_h)
             hipLaunchKernelGGL((k_nn_query<float, PtF, true>), grid, block, 0, ctx->stream, t->gf, t->pts, t->cell_start, d_q, m,
                                bound2, bounded ? (float)r_max : inf, (float *)d_dist, d_idx);
         else

@@ -194,6 +194,47 @@ __device__ __forceinline__ void nn_scan_range(const PT *__restrict__ pts, uint32
 // Per-lane work counters, compiled in only for pcr_nn_counters (STATS = true).
 struct NNStats { uint32_t rings, rows_loaded, rows_pruned, cand; };
 
+// ---- ranges with leaf / group boxes (Geom::lbox; round 6) ---------------------------------------------------------------
+// Squared distance from the query to a box of records, by the candidates' own formula: for every record p inside the box
+// |q - p| >= the clamped delta per axis, float subtraction and dist2_f32 are monotone under round-to-nearest, so this is a lower
+// bound on the COMPUTED distance of every record inside -- exactly, no slack.  A box is skipped when it exceeds `best`
+// strictly: a record AT the best distance (which could win on the smaller index) is always looked at.
+__device__ __forceinline__ float box_d2(const float4 &lo, const float4 &hi, float qx, float qy, float qz) {
+    const float dx = fmaxf(fmaxf(lo.x - qx, qx - hi.x), 0.f);
+    const float dy = fmaxf(fmaxf(lo.y - qy, qy - hi.y), 0.f);
+    const float dz = fmaxf(fmaxf(lo.z - qz, qz - hi.z), 0.f);
+    return dist2_f32(dx, dy, dz);
+}
+// Records [s, e) of `pts`: short ranges plainly; longer ones group by group (64 records) and leaf by leaf (8 records), each
+// behind its box.  A heavy cell of a LiDAR sweep (hundreds to thousands of records on one ring line) costs a few dozen box
+// tests and two or three leaves instead of every record.
+template <int B = PCR_NN_BATCH, bool STATS = false>
+__device__ __forceinline__ void nn_scan_range_lb(const PtF *__restrict__ pts, const float4 *__restrict__ lbox, const float4 *__restrict__ gbox,
+                                                 uint32_t s, uint32_t e, float qx, float qy, float qz,
+                                                 float &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr) {
+    if (e - s <= PCR_LB_MIN) {
+        if (STATS) st->cand += ((e - s + B - 1) / B) * B;
+        nn_scan_range<float, PtF, 0, B>(pts, s, e, qx, qy, qz, best, bj, borig, nullptr);
+        return;
+    }
+    const uint32_t g1 = (e - 1u) >> 6;
+    for (uint32_t G = s >> 6; G <= g1; ++G) {
+        const float4 glo = gbox[2u * G], ghi = gbox[2u * G + 1u];
+        if (STATS) st->cand += 2;
+        if (box_d2(glo, ghi, qx, qy, qz) > best) continue;
+        const uint32_t l0 = max(s >> 3, G << 3), l1 = min((e - 1u) >> 3, (G << 3) + 7u);
+        for (uint32_t L = l0; L <= l1; ++L) {
+            const float4 llo = lbox[2u * L], lhi = lbox[2u * L + 1u];
+            if (STATS) st->cand += 2;
+            if (box_d2(llo, lhi, qx, qy, qz) > best) continue;
+            const uint32_t a = max(s, L << 3), b = min(e, (L << 3) + 8u);
+            if (STATS) st->cand += ((b - a + 3) / 4) * 4;
+            nn_scan_range<float, PtF, 0, 4>(pts, a, b, qx, qy, qz, best, bj, borig, nullptr);
+        }
+    }
+}
+
+
 // ---- the search, in three pieces so that kernels can regroup lanes between them -----------------
 // Per-query geometry relative to the grid.
 template <typename Real>
@@ -234,7 +275,7 @@ __device__ __forceinline__ NNCell<Real> nn_cell(const Geom<Real> &g, Real qx, Re
 // nearly converged query (residual << halo) is certified by ring 0 alone and never enters the ring
 // loop: without the halo the ~8 % of lanes that sit closer to a face than to their match drag their
 // whole wave through ring 1 (measured: 75 % of the wave time at the converged pose).
-template <typename Real, typename PT, bool STATS = false, bool HALO = false, int TRACK = 0, int B = PCR_NN_BATCH>
+template <typename Real, typename PT, bool STATS = false, bool HALO = false, int TRACK = 0, int B = PCR_NN_BATCH, bool LB = false>
 __device__ __forceinline__ int nn_ring0(const Geom<Real> &g, const PT *__restrict__ pts, const uint32_t *__restrict__ cs,
                                         NNCell<Real> &c, Real qx, Real qy, Real qz,
                                         Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr,
@@ -254,7 +295,8 @@ __device__ __forceinline__ int nn_ring0(const Geom<Real> &g, const PT *__restric
         if (e_ > s_) {
             if (STATS) { st->rings++; st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
             uint32_t ej = PCR_NONE;
-            nn_scan_range<Real, PT, TRACK, B>((const PT *)g.pts_h, s_, e_, qx, qy, qz, best, ej, borig, tk);
+            if constexpr (LB) nn_scan_range_lb<B>((const PtF *)g.pts_h, g.lbox_h, g.gbox_h, s_, e_, qx, qy, qz, best, ej, borig);
+            else nn_scan_range<Real, PT, TRACK, B>((const PT *)g.pts_h, s_, e_, qx, qy, qz, best, ej, borig, tk);
             if (ej != PCR_NONE) bj = g.j_h[ej];
             c.reach0 = g.halo;
             // a whole-cell halo: the list held every point of rings 0 and 1; rings closer than the gap are empty anyway
@@ -264,7 +306,8 @@ __device__ __forceinline__ int nn_ring0(const Geom<Real> &g, const PT *__restric
     } else if (gap == 0) {
         const uint32_t s_ = w0 & g.cs_mask, e_ = w1 & g.cs_mask;
         if (STATS) { st->rings++; st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-        nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
+        if constexpr (LB) nn_scan_range_lb<B>(pts, g.lbox, g.gbox, s_, e_, qx, qy, qz, best, bj, borig);
+        else nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
         return 1;
     }
     if (g.seed) {                                 // a real point nearby bounds the search from the start
@@ -291,7 +334,7 @@ __device__ __forceinline__ bool nn_certified(const Geom<Real> &g, const NNCell<R
 
 // Rings kstart (>= 1) .. kmax.
 // (a tracking search prunes with tk->prune wherever the plain one prunes with best: PB below)
-template <typename Real, typename PT, bool STATS = false, int TRACK = 0, int B = PCR_NN_BATCH>
+template <typename Real, typename PT, bool STATS = false, int TRACK = 0, int B = PCR_NN_BATCH, bool LB = false>
 __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restrict__ pts, const uint32_t *__restrict__ cs,
                                          const NNCell<Real> &c, int kstart, Real qx, Real qy, Real qz,
                                          Real &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr,
@@ -338,18 +381,18 @@ __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restri
                     if (xl <= xh) {
                         const uint32_t s_ = cs[row + (uint32_t)xl] & g.cs_mask, e_ = cs[row + (uint32_t)xh + 1u] & g.cs_mask;
                         if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-                        nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
+                        if constexpr (LB) nn_scan_range_lb<B>(pts, g.lbox, g.gbox, s_, e_, qx, qy, qz, best, bj, borig); else nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
                     }
                 } else {                                    // interior row of the ring: its two end cells
                     if (xa_in && dyz2 + dxa <= PB) {
                         const uint32_t s_ = cs[row + (uint32_t)xa] & g.cs_mask, e_ = cs[row + (uint32_t)xa + 1u] & g.cs_mask;
                         if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-                        nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
+                        if constexpr (LB) nn_scan_range_lb<B>(pts, g.lbox, g.gbox, s_, e_, qx, qy, qz, best, bj, borig); else nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
                     }
                     if (xb_in && dyz2 + dxb <= PB) {
                         const uint32_t s_ = cs[row + (uint32_t)xb] & g.cs_mask, e_ = cs[row + (uint32_t)xb + 1u] & g.cs_mask;
                         if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-                        nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
+                        if constexpr (LB) nn_scan_range_lb<B>(pts, g.lbox, g.gbox, s_, e_, qx, qy, qz, best, bj, borig); else nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
                     }
                 }
             }
@@ -566,7 +609,7 @@ __device__ __forceinline__ void nn_rings_occ(const Geom<Real> &g, const PT *__re
 // TRACK: `tk` was initialised with nn_track_init(tk, bound2, mu); on return min(tk->second, tk->pmin) is a lower
 // bound on the squared distance to every target point other than the winner (to every point if there is none).
 template <typename Real, typename PT, bool STATS = false, bool SEEDED = false, bool HALO = false, int TRACK = 0, bool OCC = false,
-          int B = PCR_NN_BATCH, bool RBOX = false>
+          int B = PCR_NN_BATCH, bool RBOX = false, bool LB = false>
 __device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restrict__ pts,
                                           const uint32_t *__restrict__ cs,
                                           Real qx, Real qy, Real qz, Real bound2,
@@ -574,8 +617,11 @@ __device__ __forceinline__ void nn_search(const Geom<Real> &g, const PT *__restr
                                           NNTrack<Real> *tk = nullptr) {
     if (!SEEDED) { best = bound2; bj = PCR_NONE; borig = PCR_NONE; }
     NNCell<Real> c = nn_cell<Real>(g, qx, qy, qz, bound2);
-    const int kstart = nn_ring0<Real, PT, STATS, HALO, TRACK, B>(g, pts, cs, c, qx, qy, qz, best, bj, borig, st, tk);
-    if constexpr (RBOX) {
+    static_assert(!LB || (sizeof(Real) == 4 && TRACK == 0 && !OCC && !RBOX), "leaf / group boxes: plain float32 point search only");
+    const int kstart = nn_ring0<Real, PT, STATS, HALO, TRACK, B, LB>(g, pts, cs, c, qx, qy, qz, best, bj, borig, st, tk);
+    if constexpr (LB) {
+        nn_rings<Real, PT, STATS, TRACK, B, true>(g, pts, cs, c, kstart, qx, qy, qz, best, bj, borig, st, tk);
+    } else if constexpr (RBOX) {
         static_assert(sizeof(Real) == 4 && TRACK == 0 && !OCC, "row-block boxes: plain float32 point search only");
         nn_rings_box<STATS, B>(g, pts, cs, c, kstart, qx, qy, qz, best, bj, borig, st);
     } else if (OCC) nn_rings_occ<Real, PT, STATS, TRACK>(g, pts, cs, c, kstart, qx, qy, qz, best, bj, borig, st, tk);

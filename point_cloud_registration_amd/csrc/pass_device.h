@@ -68,6 +68,7 @@ struct LinArgs {
     const void *pts_h2;
     const uint32_t *j_h2;
     float halo2_f;
+    const float4 *lbox_h2, *gbox_h2;     // leaf / group boxes of the deeper lists (heavy targets)
 };
 
 // the geometry a point search of this launch reads: gf, with the deeper lists swapped in when the device-resident loop
@@ -75,7 +76,7 @@ struct LinArgs {
 __device__ __forceinline__ Geom<float> select_lists(const LinArgs &a) {
     Geom<float> g = a.gf;
     if (a.pose != nullptr && a.halo2_f > 0.f && __builtin_amdgcn_readfirstlane(a.pose->halo_deep) != 0) {
-        g.halo = a.halo2_f; g.cs_h = a.cs_h2; g.pts_h = a.pts_h2; g.j_h = a.j_h2;
+        g.halo = a.halo2_f; g.cs_h = a.cs_h2; g.pts_h = a.pts_h2; g.j_h = a.j_h2; g.lbox_h = a.lbox_h2; g.gbox_h = a.gbox_h2;
     }
     return g;
 }
@@ -400,7 +401,7 @@ __device__ __forceinline__ bool nn_filter_core(const LinArgs &a, float tx, float
 // FILT (voxel kinds, round 4): the centroid search runs the float32 filter search with two-way settling (nn_filter_core)
 // and falls back to the float64 search inline for what that cannot certify (a third centroid inside the margin: rare
 // enough that the extra chain does not show); HALO then says whether the FILTER index has the extended lists.
-template <int KIND, int HALO, int FILT>
+template <int KIND, int HALO, int FILT, int LB = 0>
 __device__ __forceinline__ void linearize_body(const LinArgs &a, const PoseK &P, double *acc) {
     const TileIter it(a);
     for (int64_t i = it.base; i < it.end; i += it.stride) {
@@ -411,8 +412,8 @@ __device__ __forceinline__ void linearize_body(const LinArgs &a, const PoseK &P,
         bool ok;
         if (KIND == PCR_ICP || KIND == PCR_PLANE) {
             float best;
-            nn_search<float, PtF, false, false, HALO != 0, false, false, PCR_NN_BATCH_SMALL>(a.gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f,
-                                                                                          best, bj, bo);
+            nn_search<float, PtF, false, false, HALO != 0, false, false, PCR_NN_BATCH_SMALL, false, LB != 0>(a.gf, a.pts, a.cell_start, tx, ty, tz,
+                                                                                                          a.bound2_f, best, bj, bo);
             ok = bj != PCR_NONE && __builtin_sqrtf(best) < a.md_f;                 // icp.py:34 strict gate
         } else if (FILT) {
             double d;
@@ -600,7 +601,8 @@ __device__ __forceinline__ void nn_tile_loop(const LinArgs &a, Body &&body) {
 // distance from the transformed point to every other target point, for k_certify of the next pass.  A point
 // that moved less than mu since the previous pass searches up to mu beyond its match to make that bound useful;
 // one that moved more searches exactly like the plain kernel (its bound then carries no margin).
-// RB (round 6): the rings of a plain point search prune by the target's row-block boxes (nn_rings_box)
+// RB (round 6): 1 = the rings of a plain point search prune by the target's row-block boxes (nn_rings_box); 2 = a target with
+// heavy cells: every range longer than PCR_LB_MIN records is scanned through its leaf / group boxes (nn_scan_range_lb)
 template <int VOXEL, int HALO, int TRACK, int RB = 0>
 __device__ __forceinline__ void nn_point(const LinArgs &a, const Geom<float> &gf, const PoseK &P, const PoseQ &Q, int64_t i) {
     const float x = a.sx[i], y = a.sy[i], z = a.sz[i];
@@ -633,7 +635,7 @@ __device__ __forceinline__ void nn_point(const LinArgs &a, const Geom<float> &gf
             if (pj != PCR_NONE) nn_test<float, PtF, 0>(a.pts[pj], pj, tx, ty, tz, best, bj, bo);
             nn_search<float, PtF, false, true, HALO != 0, false>(gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
 #else
-            nn_search<float, PtF, false, false, HALO != 0, false, false, PCR_NN_BATCH, RB != 0>(gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
+            nn_search<float, PtF, false, false, HALO != 0, false, false, PCR_NN_BATCH, RB == 1, RB == 2>(gf, a.pts, a.cell_start, tx, ty, tz, a.bound2_f, best, bj, bo);
 #endif
             lb2q = best;
         }

@@ -70,7 +70,15 @@ struct Geom {
     // of its cells: clouds are surfaces, and a surface fills a small part of the cells it crosses.
     const uint2 *rbox;
     int nxr;
+    // leaf / group boxes (float32 point targets with HEAVY cells, nullptr = none; round 6): lbox[2 L], lbox[2 L + 1] = min / max
+    // corner of records [8 L, 8 L + 8) of the cell-sorted array, gbox the same for records [64 G, 64 G + 64) -- fixed blocks of
+    // the ARRAY, so a block may straddle cells (its box is then looser, never wrong).  The points of a cell are sorted along a
+    // Morton curve inside the cell, so a block is a compact patch.  A range of more than PCR_LB_MIN records is scanned box by
+    // box (nn_scan_range_lb): a cell of a LiDAR sweep's inner rings holds hundreds of points where the average cell holds five.
+    // lbox_h / gbox_h: the same over the extended lists (pts_h).
+    const float4 *lbox, *gbox, *lbox_h, *gbox_h;
 };
+#define PCR_LB_MIN 24            // ranges up to this many records are scanned plainly
 #define PCR_RB_LOG 3             // cells per row block = 8
 #ifndef PCR_HALO2_FRAC
 #define PCR_HALO2_FRAC 0.25      // margin of the deeper list set, x cell
@@ -235,6 +243,7 @@ struct pcr_context {
     uint32_t *d_tile_ctr = nullptr;     // per-XCD dynamic tile counters of k_nn_scan
     int nn_blocks_per_cu[5] = {4, 4, 4, 4, 2};   // resident 256-thread blocks per CU of k_nn_scan<0/1>, k_nn_coop, k_nn_filter, k_nn_mfma
     int nn_blocks_rb = 4;               // ... of k_nn_scan<0, ., ., FULL, RB = 1> (row-block boxes)
+    int nn_blocks_lb = 4;               // ... of k_nn_scan<0, ., ., FULL, RB = 2> (leaf / group boxes)
     uint32_t filter_stamp = 0;          // stamp of the last k_nn_filter pass (k_nn_fix)
     // profiling
     bool prof_on = false;
@@ -269,6 +278,9 @@ struct pcr_target {
     uint32_t *cell_seed = nullptr;
     unsigned long long *rowocc = nullptr;   // row-occupancy bitmap of the grid (Geom::rowocc)
     uint2 *rbox = nullptr;                  // row-block boxes of a point target (Geom::rbox)
+    float4 *lbox = nullptr, *gbox = nullptr, *lbox_h = nullptr, *gbox_h = nullptr, *lbox_h2 = nullptr, *gbox_h2 = nullptr;   // Geom::lbox ...
+    int64_t pop_max = 0, pop_p99 = 0;       // largest / 99th-percentile population of an occupied cell (pcr_target_index_population)
+    bool heavy = false;                     // some cells hold far more points than the average: boxes built, box-aware search
     uint32_t *cs_h = nullptr;        // extended (halo) lists of point targets
     PtF *pts_h = nullptr;
     uint32_t *j_h = nullptr;
@@ -361,6 +373,7 @@ pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n,
                                 double halo_default = 0.1);     // halo_default: margin of the extended lists, x cell (PCR_HALO overrides)
 pcr_status pcr_build_centroid_filter(pcr_context *ctx, pcr_target *t);
 pcr_status pcr_build_deep_lists(pcr_context *ctx, pcr_target *t);
+pcr_status pcr_cell_population(pcr_context *ctx, pcr_target *t);      // fills pcr_target::pop_max / pop_p99 (once)
 pcr_status pcr_build_centroid_grid(pcr_context *ctx, const double *d_mean, int64_t n, double cell, pcr_target *t);
 pcr_status pcr_count_nonfinite(pcr_context *ctx, const void *d_xyz, int is_f64, int64_t n, int64_t *count, float *lo_out = nullptr,
                                float *hi_out = nullptr);     // (+ the bounding box of the finite points, rounded to float32)

@@ -68,17 +68,13 @@ def main(n):
             return tot
         out_g = _capi.linearize(reg._target, reg._scan_for(source), kinds[name], g2["T"], md)
         assert np.array_equal(out_g, spmd(g2["T"])), (name, "group sums != rank-ordered sum of the shards' sums")
-        # device-resident loop == host loop over the group pass
-        reg_h = make(devices=devs, native_loop=False)
-        if name == "plane":
-            reg_h.set_target(target, object(), g2["plane_normals"])
-        else:
-            reg_h.set_target(target)
-        Th = reg_h.align(source, np.eye(4))
-        assert np.array_equal(T, Th) and reg_h.last_iterations == its, (name, "device loop != host loop")
+        # device-resident loop == the C host loop (PCR_FLAG_HOST_LOOP: one pass + gn_step per iteration)
+        sc_g = reg._scan_for(source)
+        Td, itd = _capi.align(reg._target, sc_g, kinds[name], np.eye(4), reg.max_iter, reg.tol, md, _capi.FLAG_ICP_RR_QUIRK | _capi.FLAG_DEVICE_LOOP)
+        Th, ith = _capi.align(reg._target, sc_g, kinds[name], np.eye(4), reg.max_iter, reg.tol, md, _capi.FLAG_ICP_RR_QUIRK | _capi.FLAG_HOST_LOOP)
+        assert np.array_equal(Td, Th) and itd == ith == its and np.array_equal(Td, T), (name, "device loop != host loop", itd, ith, its)
         # 70 exchanges in a row: the slot index wraps at 64
         rng = np.random.default_rng(7)
-        sc_g = reg._scan_for(source)
         for i in range(70):
             Tq = np.array(g2["T"], dtype=np.float64)
             Tq[:3, 3] += rng.normal(0, 0.01, 3)

@@ -380,3 +380,62 @@ def test_g10_hip_matches_reference_at_10m(capi, g10, cname, vs):
         assert np.max(np.abs(g - g10[f"{cname}_g"][k])) <= 1e-4 * np.max(np.abs(g10[f"{cname}_g"][0])), (cname, k)
         assert abs(e2 - g10[f"{cname}_e2"][k]) <= 1e-4 * abs(g10[f"{cname}_e2"][k]), (cname, k)
     print(f"g10 {cname}: worst max|dH|/max|H| vs the reference at 10 M points {worst:.1e}")
+
+
+# ---- non-uniform density (round 6): one LiDAR revolution, density ~ 1/r^2 -------------------------------
+@pytest.fixture(scope="module")
+def lidar(capi):
+    from point_cloud_registration_amd.synthetic import lidar_sweep, perturbed_scan
+    ctx = capi.get_context(0)
+    target = lidar_sweep(1_060_000, seed=0)
+    scan, T_true = perturbed_scan(target, None, seed=2)
+    tgt = capi.Target.points(ctx, target)
+    return {"ctx": ctx, "target": target, "scan": scan, "T_true": T_true, "tgt": tgt}
+
+
+def test_lidar_sweep_is_exact(capi, orc, lidar):
+    """The heavy-cell index (cells of the sparse regime, Morton-sorted points, leaf / group boxes) returns the exhaustive search's
+    neighbour -- index AND distance, bit for bit -- at a far pose, at a near pose and for queries that are nowhere near the map;
+    the sums of a PlaneICP / ICP pass equal the oracle's.  Reference semantics: exact, unbounded 1-NN (kdtree.py:18-21)."""
+    tgt, target, scan = lidar["tgt"], lidar["target"], lidar["scan"]
+    info = tgt.index_info()
+    print("lidar index:", info)
+    assert info["heavy"] and info["pop_max"] > 20 * (info["n"] / info["occupied"])       # what the config is there to exercise
+    assert info["dims"][0] * info["dims"][1] * info["dims"][2] <= 9 * info["n"]           # the grid no longer explodes (7e8 cells in round 5)
+    rng = np.random.default_rng(11)
+    pick = rng.choice(scan.shape[0], 3000, replace=False)
+    near = np.linalg.norm(scan - np.array([-20.0, 5.0, 0.0], np.float32), axis=1) < 8.0     # the inner rings: the heaviest cells
+    pick = np.concatenate([pick, rng.choice(np.nonzero(near)[0], 1500, replace=False)])
+    for T in (np.eye(4), lidar["T_true"]):
+        q = orc.transform(T, scan[pick])
+        d, i = tgt.nn_query(q)
+        do, io = orc.nn_brute(target, q)
+        assert np.array_equal(i, io) and np.array_equal(d, do)
+    far = rng.uniform([-80, -50, -5], [80, 50, 30], (1000, 3)).astype(np.float32)         # inside, above and outside the box
+    d, i = tgt.nn_query(far)
+    do, io = orc.nn_brute(target, far)
+    assert np.array_equal(i, io) and np.array_equal(d, do)
+    # the passes themselves (search + reduce kernels on the full scan; fused kernel on a 100 k-point scan)
+    normals = tgt.estimate_normals(15, compat=True)
+    ot = orc.TargetPoints(target, normals=normals, cell=0.5)
+    for sub in (scan, scan[pick], scan[:100_000]):
+        sc = capi.Scan(lidar["ctx"], sub)
+        for T in (np.eye(4), lidar["T_true"]):
+            for kind, okind in ((capi.PLANE, orc.PLANE), (capi.ICP, orc.ICP)):
+                if sub is scan and kind == capi.ICP:
+                    continue
+                out = capi.linearize(tgt, sc, kind, T, 2.0)
+                H, g, e2, cnt = capi.unpack29(out)
+                Ho, go, e2o, cnto = orc.calc_H_g_e2(okind, ot, T, sub, 2.0, with_count=True)
+                assert cnt == cnto
+                assert rel_H(H, Ho) < 1e-9 and abs(e2 - e2o) <= 1e-9 * abs(e2o)
+        sc.close()
+
+
+def test_lidar_align_recovers_pose(capi, lidar):
+    import point_cloud_registration_amd as pcr
+    reg = pcr.PlaneICP(max_iter=30, tol=1e-3, max_dist=2.0)
+    reg.set_target(lidar["target"])
+    T = reg.align(lidar["scan"], np.eye(4))
+    dt, dang = pose_err(T, lidar["T_true"])
+    assert dt < 5e-3 and dang < 5e-4, (dt, dang, reg.last_iterations)
