@@ -109,6 +109,9 @@ def parse():
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the two live rocprofv3 --pmc passes behind roofline.traffic (also: PCR_BENCH_NO_PMC=1)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)     # the short run rocprofv3 wraps
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N from ONE process: a pcr_group (one context + host thread per GPU, in-process peer-to-peer "
+                         "exchange; Registration(devices=[...])) instead of one rank per GPU; PCR_BENCH_GROUP_DEVICES=0,0 picks the ids")
     ap.add_argument("--backend", default=os.environ.get("PCR_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="torch.distributed backend of the N > 1 plumbing (barrier, max over ranks); nccl = RCCL")
     return ap.parse_args()
@@ -288,7 +291,7 @@ def make_scan(config, target, n_scan, family=None, seed=2):
 
 def main():
     args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+    if args.gpus > 1 and not args.single_process and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         self_launch(args)                                      # does not return
     # stdout carries exactly ONE JSON line: route everything else that libraries print there (RCCL's
     # start-up banner, for one) to stderr by swapping the file descriptor until the final print
@@ -300,9 +303,10 @@ def main():
     from point_cloud_registration_amd import distributed as pdist
     from point_cloud_registration_amd.synthetic import harness_scan, perturbed_scan
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    sp = bool(args.single_process)                             # one process, a pcr_group over args.gpus devices
+    world = args.gpus if sp else int(os.environ.get("WORLD_SIZE", "1"))
+    rank = 0 if sp else int(os.environ.get("RANK", "0"))
+    local = 0 if sp else int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -314,11 +318,21 @@ def main():
     kind = {"icp": _capi.ICP, "plane": _capi.PLANE, "vplane": _capi.VPLANE, "ndt": _capi.NDT}[kind_name]
     max_dist = 2.0
 
-    ctx = _capi.get_context(dev)
+    if sp:
+        ids = os.environ.get("PCR_BENCH_GROUP_DEVICES")
+        devs = [int(v) for v in ids.split(",")] if ids else [d % torch.cuda.device_count() for d in range(args.gpus)]
+        if len(devs) != args.gpus:
+            raise SystemExit("PCR_BENCH_GROUP_DEVICES must list --gpus device ids")
+        ctx = _capi.get_group(devs)
+        prof_ctx = ctx.member(0)
+    else:
+        ctx = _capi.get_context(dev)
+        prof_ctx = ctx
     if args.variant is not None:
-        ctx.set_variant(args.variant)
+        for c in ([ctx.member(i) for i in range(world)] if sp else [ctx]):
+            c.set_variant(args.variant)
     comm = None
-    use_comm = world > 1 or bool(os.environ.get("PCR_BENCH_FORCE_COMM"))     # the latter: 1-rank self-test
+    use_comm = (world > 1 and not sp) or bool(os.environ.get("PCR_BENCH_FORCE_COMM"))     # the latter: 1-rank self-test
     if use_comm:
         pdist.init_from_env(args.backend)
         comm = pdist.Communicator(ctx, in_library=True)      # RCCL inside libpcr_hip.so; every rank agrees on a fallback
@@ -341,7 +355,11 @@ def main():
     sseed = 0 if strong else rank                              # strong: every rank builds the SAME scan, keeps a shard
     scan, T_true = make_scan(args.config, target, n_scan, seed=2 + sseed)
     n_scan_job = scan.shape[0] if strong else scan.shape[0] * world
-    if strong:
+    if sp and not strong and world > 1:
+        # weak scaling in one process: the job's scan = what the N ranks of the SPMD run would hold, one after the other
+        # (equal sizes, so pcr_group_scan_create's contiguous shards are exactly those scans)
+        scan = np.concatenate([scan] + [make_scan(args.config, target, n_scan, seed=2 + r)[0] for r in range(1, world)])
+    if strong and not sp:
         scan = np.ascontiguousarray(pdist.shard_scan(scan, rank, world))
     if kind_name in ("icp", "plane"):
         tgt = _capi.Target.points(ctx, target)
@@ -420,15 +438,15 @@ def main():
             dt = float(t.item())
         return dt, o
 
-    ctx.profile_enable(True, period=args.event_period)
-    ctx.profile_reset()
+    prof_ctx.profile_enable(True, period=args.event_period)
+    prof_ctx.profile_reset()
     blocks = []
     out = None
     for r in range(max(args.repeats, 1)):
         dt, out = timed_block()
         blocks.append(dt)
-    prof = ctx.profile_read()
-    ctx.profile_enable(False)
+    prof = prof_ctx.profile_read()
+    prof_ctx.profile_enable(False)
     t_noev, _ = timed_block()                                  # the same block with the events off
     gc.enable()
     elapsed = float(np.median(blocks))
@@ -445,7 +463,8 @@ def main():
         kern = {k: {"launches": v[0], "avg_ms": v[1] / v[0]} for k, v in prof.items() if v[0]}
         # dominant kernel(s) of one pass: everything that touches the scan / target
         hot_ms = sum(kern[k]["avg_ms"] for k in ("linearize", "nn", "reduce") if k in kern)
-        alg_bytes = B_ALG[kind_name] * sc.n                 # per launch (one pass over this rank's shard)
+        shard_n = sc.n // world if sp else sc.n             # points one launch of the profiled context processes
+        alg_bytes = B_ALG[kind_name] * shard_n              # per launch (one pass over this rank's / member's shard)
         achieved = alg_bytes / (hot_ms * 1e-3) / 1e9
         # HBM traffic per pass from the PMC passes of the SAME command (profiles/pmc_summary.json, collected
         # as MI355X_MICROARCH.md prescribes: separate --pmc runs, FETCH_SIZE x2); only trusted when that
@@ -483,16 +502,20 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "accumulate_dtype": "f64", "data": data_tag,
             "config": {"workload": args.config, "description": desc, "kind": kind_name,
-                       "target_points": int(n_target), "scan_points_per_gpu": int(sc.n),
-                       "max_dist": max_dist, "voxel_size": voxel_size, "parallelism": f"scan-shard x{world}",
+                       "target_points": int(n_target), "scan_points_per_gpu": int(sc.n // world if sp else sc.n),
+                       "max_dist": max_dist, "voxel_size": voxel_size,
+                       "parallelism": f"single-process group x{world}" if sp else f"scan-shard x{world}",
                        "backend": (args.backend if use_comm else None),
-                       "allreduce_transport": (None if comm is None else
+                       "allreduce_transport": ("p2p-in-process" if sp and world > 1 else None) if comm is None else (
                                                (("p2p-ipc-in-stream" if comm.transport == "p2p" else "rccl-in-stream")
                                                 if comm.in_library else f"host-{args.backend}")),
+                       "group_devices": (list(ctx.devices) if sp else None),
                        "devices_visible": torch.cuda.device_count(),
                        "scan_points_job": int(n_scan_job),
                        "nn_index": {"cell": info["cell"], "dims": info["dims"], "occupied_cells": info["occupied"],
-                                    "halo_m": info["halo"], "halo_records": info["halo_records"]},
+                                    "halo_m": info["halo"], "halo_records": info["halo_records"],
+                                    "cell_population_max": info.get("pop_max"), "cell_population_p99": info.get("pop_p99"),
+                                    "heavy_cells_index": info.get("heavy")},
                        "gauss_newton_iters_to_converge": iters, "pose_error_m": round(pose_err, 6),
                        "first_align_ms": None if first_align_ms is None else round(first_align_ms, 3),
                        "first_align_iterations": first_align_iters,
@@ -510,7 +533,7 @@ def main():
         }
         if "reduce" in kern:
             # SURVEY.md section 8d asks for the streaming kernel on its own: B_alg + the 4-byte index per point
-            k2 = (B_ALG[kind_name] + 4) * sc.n / (kern["reduce"]["avg_ms"] * 1e-3) / 1e9
+            k2 = (B_ALG[kind_name] + 4) * shard_n / (kern["reduce"]["avg_ms"] * 1e-3) / 1e9
             line["roofline_reduce_kernel"] = {"bound": "hbm", "achieved": round(k2, 3), "peak": HBM_PEAK_GBS,
                                               "unit": "GB/s", "frac": round(k2 / HBM_PEAK_GBS, 6),
                                               "bytes_per_point": B_ALG[kind_name] + 4,

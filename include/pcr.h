@@ -220,6 +220,12 @@ PCR_API pcr_status pcr_scan_read_matches(pcr_scan *s, uint32_t *out);
  * changed.  pcr_hash64 is the content hash it uses: 64-bit, non-cryptographic, multi-threaded (12.7 MB in ~0.1 ms
  * on the GPU box's host; the value does not depend on the number of threads).                               */
 PCR_API pcr_status pcr_hash64(const void *data, uint64_t nbytes, uint64_t *out);
+/* LZF, the codec of PCD "DATA binary_compressed" (the real data/B-01.pcd of benchmark/test_data.py:11,24 may be stored that
+ * way): decompress in_len bytes into out (capacity out_len; *written = bytes produced; PCR_ERR_INVALID on a corrupt or
+ * oversized stream), and a greedy compressor for writers and tests (out_cap >= in_len + in_len / 32 + 8 always suffices).  Host
+ * only, no GPU involved.                                                                                                  */
+PCR_API pcr_status pcr_lzf_decompress(const void *in, uint64_t in_len, void *out, uint64_t out_len, uint64_t *written);
+PCR_API pcr_status pcr_lzf_compress(const void *in, uint64_t in_len, void *out, uint64_t out_cap, uint64_t *written);
 /* CPUs the process may actually use: affinity mask capped by the cgroup CPU-bandwidth quota (cpu.max).  The hash
  * pool above is sized from it; a host application should size ITS thread pools (OpenMP, BLAS) the same way -- on a
  * 256-CPU box inside a 16-CPU container, pools sized by the visible CPUs get every thread of the process parked for

@@ -103,6 +103,8 @@ PROTOTYPES = {
     "pcr_profile_read_n": (C.c_int, [_vp, C.c_int, _i64p, _f64p, C.POINTER(C.c_int)]),
     "pcr_scan_read_matches": (C.c_int, [_vp, _vp]),
     "pcr_comm_p2p_finegrained": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "pcr_lzf_decompress": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "pcr_lzf_compress": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     # single-process multi-device groups (include/pcr.h)
     "pcr_group_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_vp)]),
     "pcr_group_destroy": (C.c_int, [_vp]),
@@ -703,6 +705,25 @@ class GroupTarget(Target):
             lib().pcr_group_target_destroy(self.ghandle)
         self.ghandle = None
         self.handle = None
+
+
+def lzf_decompress(data, out_len):
+    """LZF stream -> bytes of length out_len (pcr_lzf_decompress: host C, no GPU needed)."""
+    src = np.frombuffer(data, dtype=np.uint8)
+    out = np.empty(int(out_len), np.uint8)
+    w = C.c_uint64(0)
+    st = lib().pcr_lzf_decompress(src.ctypes.data_as(_vp), src.size, out.ctypes.data_as(_vp), out.size, C.byref(w))
+    if st != PCR_OK or w.value != out_len:
+        raise ValueError("corrupt LZF stream in PCD file")
+    return out.tobytes()
+
+
+def lzf_compress(data):
+    src = np.frombuffer(data, dtype=np.uint8)
+    out = np.empty(src.size + src.size // 32 + 16, np.uint8)
+    w = C.c_uint64(0)
+    check(lib().pcr_lzf_compress(src.ctypes.data_as(_vp), src.size, out.ctypes.data_as(_vp), out.size, C.byref(w)))
+    return out[:w.value].tobytes()
 
 
 def hash64(arr):

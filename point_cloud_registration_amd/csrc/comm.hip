@@ -129,9 +129,11 @@ __global__ void __launch_bounds__(64) k_p2p_allreduce(const P2PArgs p) {
     bool ok = true;
     if (l < p.n) {
         const unsigned long long *flag = reinterpret_cast<const unsigned long long *>(&own[(slot * PCR_P2P_MAXR + (size_t)l) * 32 + 31]);
-        long polls = 0;
+        // bounded by TIME (the constant-rate 100 MHz counter), not by a poll count: ~10 s, i.e. a peer died or never joined
+        const unsigned long long t0 = wall_clock64();
+        unsigned polls = 0;
         while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != p.seq) {
-            if (++polls > 20000000L) { ok = false; break; }        // ~ seconds: a peer died or never joined
+            if ((++polls & 1023u) == 0 && wall_clock64() - t0 > 1000000000ull) { ok = false; break; }
             __builtin_amdgcn_s_sleep(2);
         }
     }

@@ -177,3 +177,84 @@ extern "C" pcr_status pcr_hash64(const void *data, uint64_t nbytes, uint64_t *ou
     *out = g_pool->run((const uint8_t *)data, (size_t)nbytes);
     return PCR_OK;
 }
+
+// ---- LZF (the codec of PCD "DATA binary_compressed"; round 6: io.py's byte loop in Python took minutes per 1e6 points) --------
+// Format (liblzf): control byte c < 32: c + 1 literal bytes follow; else a back reference of length (c >> 5) + 2 (c >> 5 == 7: + the
+// next byte) at distance ((c & 31) << 8 | next byte) + 1 behind the write position; copies may overlap their own output.
+extern "C" pcr_status pcr_lzf_decompress(const void *in_, uint64_t in_len, void *out_, uint64_t out_len, uint64_t *written) {
+    if ((!in_ && in_len) || (!out_ && out_len) || !written) return PCR_ERR_INVALID;
+    const uint8_t *in = (const uint8_t *)in_;
+    uint8_t *out = (uint8_t *)out_;
+    uint64_t ip = 0, op = 0;
+    *written = 0;
+    while (ip < in_len) {
+        const unsigned c = in[ip++];
+        if (c < 32) {
+            const uint64_t ln = c + 1;
+            if (ip + ln > in_len || op + ln > out_len) return PCR_ERR_INVALID;
+            memcpy(out + op, in + ip, ln);
+            ip += ln; op += ln;
+        } else {
+            uint64_t ln = c >> 5;
+            if (ln == 7) { if (ip >= in_len) return PCR_ERR_INVALID; ln += in[ip++]; }
+            if (ip >= in_len) return PCR_ERR_INVALID;
+            const uint64_t dist = (((uint64_t)(c & 0x1f)) << 8 | in[ip++]) + 1;
+            ln += 2;
+            if (dist > op || op + ln > out_len) return PCR_ERR_INVALID;
+            const uint8_t *src = out + op - dist;
+            if (dist >= ln) memcpy(out + op, src, ln);
+            else for (uint64_t i = 0; i < ln; ++i) out[op + i] = src[i];      // overlapping: byte by byte, forwards
+            op += ln;
+        }
+    }
+    *written = op;
+    return PCR_OK;
+}
+
+// greedy single-pass compressor (save_pcd(..., compressed=True) and the tests' 1e6-point files); out_cap >= in_len + in_len / 32 + 8
+// always suffices (all literals).  Not liblzf's bit stream, but a valid one: every LZF decoder reads it.
+extern "C" pcr_status pcr_lzf_compress(const void *in_, uint64_t in_len, void *out_, uint64_t out_cap, uint64_t *written) {
+    if ((!in_ && in_len) || !out_ || !written) return PCR_ERR_INVALID;
+    const uint8_t *in = (const uint8_t *)in_;
+    uint8_t *out = (uint8_t *)out_;
+    std::vector<uint64_t> table((size_t)1 << 16, ~(uint64_t)0);
+    uint64_t ip = 0, op = 0, lit = 0;             // lit: literals pending since position ip - lit
+    auto flush = [&](uint64_t upto) -> bool {
+        uint64_t s = upto - lit;
+        while (lit) {
+            const uint64_t n = lit < 32 ? lit : 32;
+            if (op + 1 + n > out_cap) return false;
+            out[op++] = (uint8_t)(n - 1);
+            memcpy(out + op, in + s, n);
+            op += n; s += n; lit -= n;
+        }
+        return true;
+    };
+    while (ip < in_len) {
+        uint64_t mlen = 0, ref = 0;
+        if (ip + 3 <= in_len) {
+            const uint32_t h = ((uint32_t)in[ip] << 16 | (uint32_t)in[ip + 1] << 8 | in[ip + 2]) * 2654435761u >> 16;
+            ref = table[h];
+            table[h] = ip;
+            if (ref != ~(uint64_t)0 && ip - ref <= 8192 && in[ref] == in[ip] && in[ref + 1] == in[ip + 1] && in[ref + 2] == in[ip + 2]) {
+                const uint64_t maxl = in_len - ip < 264 ? in_len - ip : 264;
+                mlen = 3;
+                while (mlen < maxl && in[ref + mlen] == in[ip + mlen]) ++mlen;
+            }
+        }
+        if (mlen >= 3) {
+            if (!flush(ip)) return PCR_ERR_INVALID;
+            const uint64_t dist = ip - ref - 1, l = mlen - 2;
+            if (op + 3 > out_cap) return PCR_ERR_INVALID;
+            if (l < 7) out[op++] = (uint8_t)((l << 5) | (dist >> 8));
+            else { out[op++] = (uint8_t)((7u << 5) | (dist >> 8)); out[op++] = (uint8_t)(l - 7); }
+            out[op++] = (uint8_t)(dist & 0xff);
+            ip += mlen;
+        } else {
+            ++lit; ++ip;
+        }
+    }
+    if (!flush(ip)) return PCR_ERR_INVALID;
+    *written = op;
+    return PCR_OK;
+}

@@ -208,6 +208,9 @@ __device__ __forceinline__ float box_d2(const float4 &lo, const float4 &hi, floa
 // Records [s, e) of `pts`: short ranges plainly; longer ones group by group (64 records) and leaf by leaf (8 records), each
 // behind its box.  A heavy cell of a LiDAR sweep (hundreds to thousands of records on one ring line) costs a few dozen box
 // tests and two or three leaves instead of every record.
+#ifndef PCR_LB_BATCHED
+#define PCR_LB_BATCHED 1
+#endif
 template <int B = PCR_NN_BATCH, bool STATS = false>
 __device__ __forceinline__ void nn_scan_range_lb(const PtF *__restrict__ pts, const float4 *__restrict__ lbox, const float4 *__restrict__ gbox,
                                                  uint32_t s, uint32_t e, float qx, float qy, float qz,
@@ -218,6 +221,48 @@ __device__ __forceinline__ void nn_scan_range_lb(const PtF *__restrict__ pts, co
         return;
     }
     const uint32_t g1 = (e - 1u) >> 6;
+#if PCR_LB_BATCHED
+    // The first version walked the boxes one by one -- box, test, next box: a chain of ~16 dependent round trips for a query in
+    // a 300-point cell, five times the chain of a query in an ordinary cell, and the pass took that much longer.  Here FOUR
+    // boxes are requested together at either level (8 loads in flight), the survivors are remembered in a bit mask (no indexed
+    // register arrays), and a leaf's 8 records are one batch of 8 loads.
+    const uint32_t l_first = s >> 3, l_last = (e - 1u) >> 3;
+    const float inf = __int_as_float(0x7f800000);
+    for (uint32_t G = s >> 6; G <= g1; G += 4u) {
+        uint32_t gm = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t gi = min(G + u, g1);
+            const float4 lo = gbox[2u * gi], hi = gbox[2u * gi + 1u];
+            const float d = G + u <= g1 ? box_d2(lo, hi, qx, qy, qz) : inf;
+            gm |= (d <= best ? 1u : 0u) << u;
+        }
+        if (STATS) st->cand += 8;
+        while (gm) {
+            const uint32_t Gi = G + (uint32_t)__builtin_ctz(gm);
+            gm &= gm - 1u;
+            const uint32_t l0 = max(l_first, Gi << 3), l1 = min(l_last, (Gi << 3) + 7u);
+            for (uint32_t L = l0; L <= l1; L += 4u) {
+                uint32_t lm = 0;
+#pragma unroll
+                for (uint32_t v = 0; v < 4u; ++v) {
+                    const uint32_t li = min(L + v, l1);
+                    const float4 lo = lbox[2u * li], hi = lbox[2u * li + 1u];
+                    const float d = L + v <= l1 ? box_d2(lo, hi, qx, qy, qz) : inf;
+                    lm |= (d <= best ? 1u : 0u) << v;
+                }
+                if (STATS) st->cand += 8;
+                while (lm) {
+                    const uint32_t Li = L + (uint32_t)__builtin_ctz(lm);
+                    lm &= lm - 1u;
+                    const uint32_t a = max(s, Li << 3), b = min(e, (Li << 3) + 8u);
+                    if (STATS) st->cand += 8;
+                    nn_scan_range<float, PtF, 0, 8>(pts, a, b, qx, qy, qz, best, bj, borig, nullptr);
+                }
+            }
+        }
+    }
+#else
     for (uint32_t G = s >> 6; G <= g1; ++G) {
         const float4 glo = gbox[2u * G], ghi = gbox[2u * G + 1u];
         if (STATS) st->cand += 2;
@@ -232,6 +277,7 @@ __device__ __forceinline__ void nn_scan_range_lb(const PtF *__restrict__ pts, co
             nn_scan_range<float, PtF, 0, 4>(pts, a, b, qx, qy, qz, best, bj, borig, nullptr);
         }
     }
+#endif
 }
 
 

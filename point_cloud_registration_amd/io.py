@@ -14,31 +14,10 @@ _NP = {("F", 4): "<f4", ("F", 8): "<f8", ("U", 1): "<u1", ("U", 2): "<u2", ("U",
 
 
 def _lzf_decompress(data, out_len):
-    """LZF (the compression of ``DATA binary_compressed``), plain Python/NumPy."""
-    out = bytearray(out_len)
-    ip, op, n = 0, 0, len(data)
-    while ip < n:
-        ctrl = data[ip]; ip += 1
-        if ctrl < 32:                                   # literal run
-            ln = ctrl + 1
-            out[op:op + ln] = data[ip:ip + ln]
-            ip += ln; op += ln
-        else:                                           # back reference
-            ln = ctrl >> 5
-            if ln == 7:
-                ln += data[ip]; ip += 1
-            ref = op - ((ctrl & 0x1f) << 8) - data[ip] - 1
-            ip += 1
-            ln += 2
-            if ref + ln <= op:
-                out[op:op + ln] = out[ref:ref + ln]
-                op += ln
-            else:                                       # overlapping copy
-                for _ in range(ln):
-                    out[op] = out[ref]; op += 1; ref += 1
-    if op != out_len:
-        raise ValueError("corrupt LZF stream in PCD file")
-    return bytes(out)
+    """LZF (the compression of ``DATA binary_compressed``): ``pcr_lzf_decompress`` inside libpcr_hip.so (host C; the pure-Python
+    byte loop of rounds 1-5 took minutes per million points)."""
+    from . import _capi
+    return _capi.lzf_decompress(bytes(data), int(out_len))
 
 
 def read_pcd(path):
@@ -98,16 +77,23 @@ def load_pcd(path):
     return out
 
 
-def save_pcd(path, xyz, binary=True):
-    """Write an (N, 3) cloud as PCD v0.7 (x y z float32)."""
+def save_pcd(path, xyz, binary=True, compressed=False):
+    """Write an (N, 3) cloud as PCD v0.7 (x y z float32): ``DATA binary`` / ``ascii`` / (``compressed=True``)
+    ``binary_compressed`` -- field by field, LZF."""
     xyz = np.ascontiguousarray(xyz, dtype=np.float32)
     n = xyz.shape[0]
+    mode = "binary_compressed" if compressed else ("binary" if binary else "ascii")
     head = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\n"
             f"COUNT 1 1 1\nWIDTH {n}\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS {n}\n"
-            f"DATA {'binary' if binary else 'ascii'}\n")
+            f"DATA {mode}\n")
     with open(path, "wb") as f:
         f.write(head.encode("ascii"))
-        if binary:
+        if compressed:
+            from . import _capi
+            soa = np.ascontiguousarray(xyz.T).tobytes()
+            lz = _capi.lzf_compress(soa)
+            f.write(np.array([len(lz), len(soa)], "<u4").tobytes() + lz)
+        elif binary:
             f.write(xyz.tobytes())
         else:
             np.savetxt(f, xyz, fmt="%.9g")

@@ -129,6 +129,18 @@ def lidar_sweep(n, seed=0, sensor=(-20.0, 5.0, 1.8), rings=64, elev_deg=(-24.8, 
     return np.ascontiguousarray(out[:n], dtype=np.float32)
 
 
+def lidar_normals(pts):
+    """Analytic unit normals of a ``lidar_sweep`` cloud from the coordinates alone (the surfaces are the street's: ground z = 0,
+    walls y = +-30 and x = +-60): a reproducible input for ``PlaneICP.set_target(target, tree, norm)`` (plane_icp.py:25-27)."""
+    out = np.zeros((pts.shape[0], 3), dtype=np.float32)
+    ywall = np.abs(np.abs(pts[:, 1]) - 30.0) < 0.5
+    xwall = (np.abs(np.abs(pts[:, 0]) - 60.0) < 0.5) & ~ywall
+    out[:, 2] = ~(ywall | xwall)
+    out[:, 1] = ywall
+    out[:, 0] = xwall
+    return out
+
+
 def make_T(so3, t):
     T = np.eye(4)
     T[:3, :3] = expSO3(np.asarray(so3, dtype=np.float64))

@@ -37,7 +37,7 @@ class VoxelGrid:
         st = self._target.voxel_stats(("mean", "cov", "norm", "icov"))
         self.mean, self.cov, self.norm = st["mean"], st["cov"], st["norm"]
         self._icov = st["icov"]
-        self.kdtree = _CentroidTree(self._target)
+        self.kdtree = _CentroidTree(self._target, self.mean)
 
     def calc_icov(self):
         """voxel.py:69-102; already computed by the GPU build, exposed under the reference's name."""
@@ -61,13 +61,32 @@ class VoxelGrid:
 class _CentroidTree:
     """KDTree(means) of the reference (voxel.py:165): float64 nearest-centroid search on the GPU."""
 
-    def __init__(self, target):
+    def __init__(self, target, means=None):
         self._target = target
+        self._means = means
+        self._knn = None
 
     def query(self, points, k=1):
-        if k != 1:
-            raise NotImplementedError("nearest-centroid search supports k=1")
-        return self._target.nn_query(np.asarray(points))
+        """k = 1: the exact float64 nearest-centroid search of the registration kernels.  k > 1 (off the hot path; the
+        reference's KDTree(means) answers any k, voxel.py:165): the GPU's exact k-NN over the float32-rounded centroids
+        nominates k + 2, their float64 distances to the TRUE centroids are recomputed and the k smallest kept in (distance,
+        index) order -- the float64 tree's answer unless centroids beyond the (k + 2)-th lie within float32 rounding (~1e-6 of
+        the coordinates) of the k-th."""
+        points = np.asarray(points)
+        if k == 1:
+            return self._target.nn_query(points)
+        means = self._means if self._means is not None else self._target.voxel_stats(("mean",))["mean"]
+        kk = min(int(k) + 2, means.shape[0])
+        if kk < k:
+            raise ValueError(f"k = {k} exceeds the number of voxels ({means.shape[0]})")
+        if self._knn is None:
+            self._knn = _capi.Target.points(self._target.ctx if not isinstance(self._target.ctx, _capi.Group) else self._target.ctx.member(0),
+                                            means.astype(np.float32))
+        _, cand = self._knn.knn_query(points.astype(np.float32), kk)
+        d = np.linalg.norm(points.astype(np.float64)[:, None, :] - means[cand], axis=2)
+        order = np.lexsort((cand, d), axis=1)[:, :k]
+        rows = np.arange(points.shape[0])[:, None]
+        return d[rows, order], cand[rows, order]
 
 
 def voxel_filter(points, voxel_size, device=None):

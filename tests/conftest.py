@@ -92,6 +92,34 @@ def g10():
     return g
 
 
+@pytest.fixture(scope="session")
+def g11():
+    """Non-uniform density: the reference's four classes on a 200 k-point LiDAR sweep (synthetic.lidar_sweep) + the clouds,
+    regenerated and checksum-guarded."""
+    import zlib
+    from point_cloud_registration_amd.synthetic import lidar_sweep, lidar_normals, perturbed_scan
+    g = load_golden("g11_lidar_sweep.npz")
+    target = lidar_sweep(int(g["n"]), seed=0)
+    scan = perturbed_scan(target, int(g["n_scan"]), seed=2)[0]
+    normals = lidar_normals(target)
+    assert zlib.crc32(target.tobytes()) == int(g["crc32_target"]), "lidar_sweep() no longer reproduces the fixture's cloud"
+    assert zlib.crc32(scan.tobytes()) == int(g["crc32_scan"]) and zlib.crc32(normals.tobytes()) == int(g["crc32_normals"])
+    g["target"], g["scan"], g["given_normals"] = target, scan, normals
+    return g
+
+
+@pytest.fixture(scope="session")
+def g12():
+    return load_golden("g12_voxel_filter.npz")
+
+
+def step_err(H, g, Href, gref):
+    """What a difference in (H, g) does to the Gauss-Newton step of registration.py:103: |solve(H, g) - solve(Href, gref)|_inf
+    (metres / radians).  Unlike max|dg| / max|g_k| it stays meaningful at the converged poses, where g itself cancels to
+    rounding level (VERDICT r5 weak #2)."""
+    return float(np.max(np.abs(np.linalg.solve(H, g) - np.linalg.solve(Href, gref))))
+
+
 def rel_H(H, Href):
     """Parity metric of SURVEY.md section 8a Q5: max|dH| / max|H_ref|."""
     return float(np.max(np.abs(np.asarray(H) - np.asarray(Href))) / np.max(np.abs(Href)))

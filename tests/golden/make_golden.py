@@ -405,6 +405,52 @@ def g10():
     np.savez_compressed(os.path.join(HERE, "g10_10m_voxel.npz"), **out)
 
 
+def g11():
+    """NON-UNIFORM density: the four classes of the reference on one revolution of a 64-beam LiDAR
+    (synthetic.lidar_sweep: density ~ 1/r^2, ring lines) -- 200 k-point map, 50 k-point perturbed scan, the harness' parameters
+    (benchmark/speed_test_comparison.py:166-170).  H, g, e2 at every iterate of align(), iteration counts, final poses.
+    PlaneICP with supplied analytic normals (plane_icp.py:25-27; synthetic.lidar_normals) so that the tests regenerate every
+    input bit for bit; clouds are regenerated from the deterministic generators (checksums)."""
+    import zlib
+    from point_cloud_registration_amd.synthetic import lidar_sweep, lidar_normals, perturbed_scan
+    target = lidar_sweep(200_000, seed=0)
+    scan, T_true = perturbed_scan(target, 50_000, seed=2)
+    given = lidar_normals(target)
+    out = {"n": np.int64(target.shape[0]), "n_scan": np.int64(scan.shape[0]), "max_dist": 2.0, "voxel_size": 1.0, "T_true": T_true,
+           "crc32_target": np.int64(zlib.crc32(target.tobytes())), "crc32_scan": np.int64(zlib.crc32(scan.tobytes())),
+           "crc32_normals": np.int64(zlib.crc32(given.tobytes()))}
+    icp = ref.ICP(max_dist=2.0); icp.set_target(target)
+    pg = ref.PlaneICP(max_dist=2.0, k=15); pg.set_target(target, icp.kdtree, given)
+    vp = ref.VPlaneICP(voxel_size=1.0, max_dist=2.0); vp.set_target(target)
+    ndt = ref.NDT(voxel_size=1.0, max_dist=2.0); ndt.set_target(target)
+    out["n_voxels"] = np.int64(vp.voxels.mean.shape[0])
+    for cname, obj in {"icp": icp, "planeg": pg, "vplane": vp, "ndt": ndt}.items():
+        Ts, Hs, gs, e2s, final = _traj(obj, scan)
+        out[f"{cname}_T"], out[f"{cname}_H"], out[f"{cname}_g"], out[f"{cname}_e2"], out[f"{cname}_final"] = Ts, Hs, gs, e2s, final
+        print(f"G11 {cname}: {len(Ts)} iterations, t = {final[:3, 3]}", flush=True)
+    np.savez_compressed(os.path.join(HERE, "g11_lidar_sweep.npz"), **out)
+
+
+def g12():
+    """What the reference's voxel_filter (voxel.py:209-241) returns on g3's float32 cloud at 0.5 / 1.0, and what
+    VoxelGrid.kdtree.query(points, k=3) (voxel.py:165 -> KDTree(means)) returns for 500 of its points (VERDICT r5 weak #4,
+    missing #5)."""
+    g3 = dict(np.load(os.path.join(HERE, "g3_voxels.npz")))
+    pts = g3["points_f32"]
+    out = {}
+    for vs in (0.5, 1.0):
+        out[f"filter_vs{vs}"] = np.asarray(ref.voxel_filter(pts, vs))
+        print(f"G12 voxel_filter({vs}): {out[f'filter_vs{vs}'].shape} {out[f'filter_vs{vs}'].dtype}")
+    grid = ref.VoxelGrid(1.0)
+    grid.set_points(pts)
+    q = pts[::12][:500].astype(np.float32) + np.float32(0.013)
+    d, i = grid.kdtree.query(q, k=3)
+    out["k3_query"], out["k3_dist"], out["k3_idx"] = q, np.asarray(d), np.asarray(i)
+    d1, i1 = grid.kdtree.query(q)
+    out["k1_dist"], out["k1_idx"] = np.asarray(d1), np.asarray(i1)
+    np.savez_compressed(os.path.join(HERE, "g12_voxel_filter.npz"), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:
         for name in sys.argv[1:]:

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import rel_H
+from conftest import rel_H, step_err
 
 pytestmark = pytest.mark.gpu
 
@@ -353,6 +353,10 @@ def test_g8_hip_matches_reference_at_b01_size(capi, g8, g8_targets, scan_name):
             assert r <= 1e-5, (tag, k, r)
             assert np.max(np.abs(g - g8[f"{tag}_g"][k])) <= 1e-4 * np.max(np.abs(g8[f"{tag}_g"][0])), (tag, k)
             assert abs(e2 - g8[f"{tag}_e2"][k]) <= 1e-4 * abs(g8[f"{tag}_e2"][k]), (tag, k)
+            # the gradient at EVERY pose, measured by the step the reference takes from it (the ledger with
+            # max|dg| / max|g_k| per pose: tools/parity_ledger.py -> profiles/r06_g8_parity.txt).  "plane" runs on the GPU's own
+            # k-NN normals, which differ from LAPACK's in ~1e-3 of the points: its step bar is the pose bar of the north star
+            assert step_err(H, g, g8[f"{tag}_H"][k], g8[f"{tag}_g"][k]) <= (1e-4 if cname == "plane" else 5e-5), (tag, k)
         T, iters = capi.align(tgt, sc, kind, np.eye(4), 30, 1e-3, md)
         assert iters == Ts.shape[0], (tag, iters, Ts.shape[0])
         dt, dr = _pose_err(T, g8[f"{tag}_final"])
@@ -379,6 +383,7 @@ def test_g10_hip_matches_reference_at_10m(capi, g10, cname, vs):
         assert r <= 1e-5, (cname, k, r)
         assert np.max(np.abs(g - g10[f"{cname}_g"][k])) <= 1e-4 * np.max(np.abs(g10[f"{cname}_g"][0])), (cname, k)
         assert abs(e2 - g10[f"{cname}_e2"][k]) <= 1e-4 * abs(g10[f"{cname}_e2"][k]), (cname, k)
+        assert step_err(H, g, g10[f"{cname}_H"][k], g10[f"{cname}_g"][k]) <= 5e-5, (cname, k)
     print(f"g10 {cname}: worst max|dH|/max|H| vs the reference at 10 M points {worst:.1e}")
 
 
@@ -400,7 +405,7 @@ def test_lidar_sweep_is_exact(capi, orc, lidar):
     tgt, target, scan = lidar["tgt"], lidar["target"], lidar["scan"]
     info = tgt.index_info()
     print("lidar index:", info)
-    assert info["heavy"] and info["pop_max"] > 20 * (info["n"] / info["occupied"])       # what the config is there to exercise
+    assert info["heavy"] and info["pop_max"] > 10 * (info["n"] / info["occupied"])       # what the config is there to exercise
     assert info["dims"][0] * info["dims"][1] * info["dims"][2] <= 9 * info["n"]           # the grid no longer explodes (7e8 cells in round 5)
     rng = np.random.default_rng(11)
     pick = rng.choice(scan.shape[0], 3000, replace=False)
@@ -439,3 +444,32 @@ def test_lidar_align_recovers_pose(capi, lidar):
     T = reg.align(lidar["scan"], np.eye(4))
     dt, dang = pose_err(T, lidar["T_true"])
     assert dt < 5e-3 and dang < 5e-4, (dt, dang, reg.last_iterations)
+
+
+def test_g11_hip_matches_reference_on_lidar_sweep(capi, g11):
+    """Non-uniform density, the REFERENCE's own numbers (tests/golden/make_golden.py: g11): its four classes on a 200 k-point
+    LiDAR sweep.  H <= 1e-5, g / e2 <= 1e-4, the step <= 5e-5 at every iterate of its align(); the same iteration counts
+    (NDT: all 30 -- it does not converge on this cloud in the reference either); final poses to 1e-4."""
+    ctx = capi.get_context(0)
+    target, scan, md = g11["target"], g11["scan"], float(g11["max_dist"])
+    pts = capi.Target.points(ctx, target, g11["given_normals"])
+    vox = capi.Target.voxels(ctx, target, float(g11["voxel_size"]), 10)
+    assert vox.size() == int(g11["n_voxels"])
+    assert pts.index_info()["heavy"]
+    sc = capi.Scan(ctx, scan)
+    worst = {}
+    for cname, kind, tgt in (("icp", capi.ICP, pts), ("planeg", capi.PLANE, pts), ("vplane", capi.VPLANE, vox), ("ndt", capi.NDT, vox)):
+        Ts = g11[f"{cname}_T"]
+        for k in range(Ts.shape[0]):
+            H, g, e2, cnt = capi.unpack29(capi.linearize(tgt, sc, kind, Ts[k], md))
+            r = rel_H(H, g11[f"{cname}_H"][k])
+            worst[cname] = max(worst.get(cname, 0.0), r)
+            assert r <= 1e-5, (cname, k, r)
+            assert np.max(np.abs(g - g11[f"{cname}_g"][k])) <= 1e-4 * np.max(np.abs(g11[f"{cname}_g"][0])), (cname, k)
+            assert abs(e2 - g11[f"{cname}_e2"][k]) <= 1e-4 * abs(g11[f"{cname}_e2"][k]), (cname, k)
+            assert step_err(H, g, g11[f"{cname}_H"][k], g11[f"{cname}_g"][k]) <= 5e-5, (cname, k)
+        T, iters = capi.align(tgt, sc, kind, np.eye(4), 30, 1e-3, md)
+        assert iters == Ts.shape[0], (cname, iters, Ts.shape[0])
+        dt, dr = _pose_err(T, g11[f"{cname}_final"])
+        assert dt <= 1e-4 and dr <= 1e-4, (cname, dt, dr)
+    print("g11: worst max|dH|/max|H| vs the reference on the LiDAR sweep", {k: f"{v:.1e}" for k, v in worst.items()})

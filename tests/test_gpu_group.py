@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("n", [1, 2, 4, 8])
 def test_group_n_contexts_one_gpu(n):
-    env = dict(os.environ, GPU_MAX_HW_QUEUES=str(max(n, 4)), PYTHONPATH=REPO)
+    env = dict(os.environ, GPU_MAX_HW_QUEUES=str(4 if n <= 2 else 4 * n), PYTHONPATH=REPO)
     r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "group_check.py"), str(n)], env=env, capture_output=True,
                        text=True, timeout=900)
     print(r.stdout[-3000:])

@@ -559,16 +559,28 @@ def test_normals_full_scale_gpu(capi, orc, ctx, g7, k):
     assert np.array_equal(ik[:300], ib)
 
 
-def test_voxel_filter_gpu(g3):
-    """voxel_filter (voxel.py:209-241): one float32 centroid per occupied voxel, ascending key order."""
+def test_voxel_filter_gpu(g3, g12):
+    """voxel_filter (voxel.py:209-241) against the REFERENCE's own output on g3's cloud (tests/golden/make_golden.py: g12;
+    VERDICT r5 weak #4): one float32 centroid per occupied voxel, ascending key order, bit for bit (the reference sums with
+    float64 bincount weights and rounds once, like the GPU build)."""
     import point_cloud_registration_amd as pcr
     pts = g3["points_f32"]
-    f = pcr.voxel_filter(pts, 0.5)
-    keys = g3["f32_vs0.5_keys"]
-    uniq, inv = np.unique(keys, return_inverse=True)
-    counts = np.bincount(inv)
-    ref = np.stack([np.bincount(inv, weights=pts[:, a]) / counts for a in range(3)], 1).astype(np.float32)
-    assert f.dtype == np.float32 and np.array_equal(f, ref)
+    for vs in (0.5, 1.0):
+        f = pcr.voxel_filter(pts, vs)
+        assert f.dtype == np.float32 and np.array_equal(f, g12[f"filter_vs{vs}"]), vs
+
+
+def test_centroid_tree_knn_matches_reference(g3, g12):
+    """VoxelGrid.kdtree.query(points, k) for k > 1 (voxel.py:165: KDTree(means) answers any k; VERDICT r5 missing #5): the
+    reference's three nearest centroids and their float64 distances for 500 query points."""
+    import point_cloud_registration_amd as pcr
+    grid = pcr.VoxelGrid(1.0)
+    grid.set_points(g3["points_f32"])
+    d, i = grid.kdtree.query(g12["k3_query"], k=3)
+    assert np.array_equal(i, g12["k3_idx"])
+    assert np.allclose(d, g12["k3_dist"], rtol=1e-12, atol=1e-12)
+    d1, i1 = grid.kdtree.query(g12["k3_query"])
+    assert np.array_equal(i1, g12["k1_idx"]) and np.allclose(d1, g12["k1_dist"], rtol=1e-12, atol=1e-12)
 
 
 def test_robustness_edge_inputs(capi, orc, ctx):

@@ -4,7 +4,7 @@
 import numpy as np
 import pytest
 
-from conftest import rel_H
+from conftest import step_err, rel_H
 from oracle import oracle as orc
 
 KINDS = {"icp": orc.ICP, "plane": orc.PLANE, "vplane": orc.VPLANE, "ndt": orc.NDT}
@@ -211,14 +211,40 @@ def test_g8_oracle_matches_reference_at_b01_size(g8, scan_name):
         for k in range(Ts.shape[0]):
             H, g, e2 = orc.calc_H_g_e2(kind, tgt, Ts[k], scan, md)
             assert rel_H(H, g8[f"{tag}_H"][k]) <= 1e-5, (tag, k, rel_H(H, g8[f"{tag}_H"][k]))
-            # g cancels towards convergence: relative to the gradient at the start of the run
+            # g cancels towards convergence: relative to the gradient at the start of the run ...
             assert np.max(np.abs(g - g8[f"{tag}_g"][k])) <= 1e-4 * np.max(np.abs(g8[f"{tag}_g"][0])), (tag, k)
+            # ... and, at EVERY pose, by what it does to the step the reference takes from here
+            assert step_err(H, g, g8[f"{tag}_H"][k], g8[f"{tag}_g"][k]) <= 5e-5, (tag, k)
             assert abs(e2 - g8[f"{tag}_e2"][k]) <= 1e-4 * abs(g8[f"{tag}_e2"][k]), (tag, k)
         trace = []
         T = orc.align(kind, tgt, scan, max_iter=30, tol=1e-3, max_dist=md, trace=trace)
         assert len(trace) == Ts.shape[0], (tag, len(trace), Ts.shape[0])
         dt, dr = _pose_err(T, g8[f"{tag}_final"])
         assert dt <= 1e-4 and dr <= 1e-4, (tag, dt, dr)
+
+
+def test_g11_oracle_matches_reference_on_lidar_sweep(g11):
+    """Non-uniform density: the reference's four classes on one LiDAR revolution (density ~ 1/r^2, ring
+    lines; 200 k-point map, 50 k-point scan).  H <= 1e-5, the Gauss-Newton step <= 5e-5 at every iterate of the reference's own
+    align() -- including NDT's 30 iterations, which do NOT converge on this cloud in the reference either (singular voxel
+    covariances on line-shaped voxels, ndt.py:24-57 has no regularisation): parity means following it there."""
+    target, scan, md = g11["target"], g11["scan"], float(g11["max_dist"])
+    tp = orc.TargetPoints(target, normals=g11["given_normals"], cell=0.5)
+    tv = orc.TargetVoxels(target, float(g11["voxel_size"]))
+    assert tv.mean.shape[0] == int(g11["n_voxels"])
+    for cname, kind, tgt in (("icp", orc.ICP, tp), ("planeg", orc.PLANE, tp), ("vplane", orc.VPLANE, tv), ("ndt", orc.NDT, tv)):
+        Ts = g11[f"{cname}_T"]
+        for k in range(Ts.shape[0]):
+            H, g, e2 = orc.calc_H_g_e2(kind, tgt, Ts[k], scan, md)
+            assert rel_H(H, g11[f"{cname}_H"][k]) <= 1e-5, (cname, k)
+            assert np.max(np.abs(g - g11[f"{cname}_g"][k])) <= 1e-4 * np.max(np.abs(g11[f"{cname}_g"][0])), (cname, k)
+            assert abs(e2 - g11[f"{cname}_e2"][k]) <= 1e-4 * abs(g11[f"{cname}_e2"][k]), (cname, k)
+            assert step_err(H, g, g11[f"{cname}_H"][k], g11[f"{cname}_g"][k]) <= 5e-5, (cname, k)
+        trace = []
+        T = orc.align(kind, tgt, scan, max_iter=30, tol=1e-3, max_dist=md, trace=trace)
+        assert len(trace) == Ts.shape[0], (cname, len(trace), Ts.shape[0])
+        dt, dr = _pose_err(T, g11[f"{cname}_final"])
+        assert dt <= 1e-4 and dr <= 1e-4, (cname, dt, dr)
 
 
 @pytest.mark.parametrize("cname,vs", [("vplane", 0.5), ("ndt", 1.0)])
