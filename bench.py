@@ -41,7 +41,7 @@ import time
 # Host hygiene, before NumPy loads its BLAS: on a 256-CPU box inside a container with a 16-CPU quota the BLAS thread
 # pool (one spinning thread per visible CPU after the first matmul) exhausts the cgroup's CPU bandwidth and the
 # kernel parks EVERY thread of the process for the rest of the 100 ms period -- the "12-42 ms launch stalls" of
-# round 2 (root-caused in round 3: profiles/r03_stall_root_cause.txt).  The oracle's OpenMP pool (cpu_baseline) is
+# round 2 (root-caused in round 3: profiles/archive/r03_stall_root_cause.txt).  The oracle's OpenMP pool (cpu_baseline) is
 # not affected by this variable.
 os.environ.setdefault("OPENBLAS_NUM_THREADS", "8")
 
@@ -363,7 +363,14 @@ def main():
         scan = np.ascontiguousarray(pdist.shard_scan(scan, rank, world))
     if kind_name in ("icp", "plane"):
         tgt = _capi.Target.points(ctx, target)
-        if kind_name == "plane":
+        if kind_name == "plane" and "lidar" in args.config:
+            # PlaneICP.set_target(target, tree, normals) (plane_icp.py:25-27; what the reference's own benchmark does,
+            # speed_test_comparison.py:25-32): k = 15 neighbours of a sweep's ring LINES are collinear, their PCA normal is
+            # arbitrary and PlaneICP -- the reference's included -- converges to a wrong pose on them
+            from point_cloud_registration_amd.synthetic import lidar_normals
+            lidar_n = lidar_normals(target)
+            tgt.set_normals(lidar_n)
+        elif kind_name == "plane":
             # reference default k=15 (plane_icp.py:14).  The reference's float32 single-pass covariance
             # (estimate_normals.py:56-72) is kept where it works (|p| <= 60 m); at the 100 M cloud's
             # |p| ~ 600 m it loses every digit, so that config uses the centred float64 form
@@ -388,7 +395,9 @@ def main():
         t0 = time.perf_counter()
         if kind_name in ("icp", "plane"):
             tgt2 = _capi.Target.points(ctx, target)
-            if kind_name == "plane":
+            if kind_name == "plane" and "lidar" in args.config:
+                tgt2.set_normals(lidar_n)
+            elif kind_name == "plane":
                 tgt2.estimate_normals(15, compat=n_target <= 2_000_000, want=False)
         else:
             tgt2 = _capi.Target.voxels(ctx, target, voxel_size, 10)

@@ -988,7 +988,7 @@ static pcr_status wait_host_word(pcr_context *ctx, Pred ready, const char *what)
 }
 
 // Rare 6-60 ms stalls of ONE call early in a process ("12-42 ms, about once per 1500 passes") were
-// root-caused in round 3 (tools/stall_study.py, PCR_STALL_DEBUG=1; profiles/r03_stall_root_cause.txt): the calling
+// root-caused in round 3 (tools/stall_study.py, PCR_STALL_DEBUG=1; profiles/archive/r03_stall_root_cause.txt): the calling
 // thread is DESCHEDULED -- on a CPU for 0.03-0.08 ms of a 41 ms stall -- while the container's cgroup reports one
 // more throttled period (cpu.max = 16 CPUs per 100 ms on the GPU box): the thread pools of the host libraries
 // (256 visible CPUs) burn the CPU quota during start-up and the kernel parks every thread of the cgroup until the

@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(256) k_nn_coop(const LinArgs a) {
 // work counters of the search (instrumentation; same traversal as k_nn_scan<0>): out[0..3] = per-lane
 // sums of rings, rows loaded, rows pruned by arithmetic, candidates tested; out[4..7] = the same with
 // the per-WAVE maximum charged to all 64 lanes (what the SIMD actually executes under divergence)
-template <int HALO>
+template <int HALO, bool LB = false>
 __global__ void __launch_bounds__(256) k_nn_counters(const LinArgs a, unsigned long long *out) {
     const TileIter it(a);
     unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -215,10 +215,10 @@ __global__ void __launch_bounds__(256) k_nn_counters(const LinArgs a, unsigned l
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         const unsigned long long t1 = __builtin_readcyclecounter();
         int kstart = 0;
-        if (live) kstart = nn_ring0<float, PtF, true, HALO != 0>(a.gf, a.pts, a.cell_start, c, tx, ty, tz, best, bj, bo, &st);
+        if (live) kstart = nn_ring0<float, PtF, true, HALO != 0, 0, PCR_NN_BATCH, LB>(a.gf, a.pts, a.cell_start, c, tx, ty, tz, best, bj, bo, &st);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         const unsigned long long t2 = __builtin_readcyclecounter();
-        if (live) nn_rings<float, PtF, true>(a.gf, a.pts, a.cell_start, c, kstart, tx, ty, tz, best, bj, bo, &st);
+        if (live) nn_rings<float, PtF, true, 0, PCR_NN_BATCH, LB>(a.gf, a.pts, a.cell_start, c, kstart, tx, ty, tz, best, bj, bo, &st);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         const unsigned long long t3 = __builtin_readcyclecounter();
         cyc[0] += t1 - t0; cyc[1] += t2 - t1; cyc[2] += t3 - t2;
@@ -355,7 +355,9 @@ extern "C" pcr_status pcr_nn_counters(pcr_target *t, pcr_scan *s, const double T
     DevBuf<unsigned long long> d;
     HIP_TRY(d.alloc(11));
     HIP_TRY(hipMemsetAsync(d.p, 0, sizeof h, ctx->stream));
-    if (t->cs_h) hipLaunchKernelGGL(k_nn_counters<1>, dim3(a.nblocks), dim3(256), 0, ctx->stream, a, d.p);
+    if (t->gf.lbox && t->cs_h) hipLaunchKernelGGL((k_nn_counters<1, true>), dim3(a.nblocks), dim3(256), 0, ctx->stream, a, d.p);
+    else if (t->gf.lbox) hipLaunchKernelGGL((k_nn_counters<0, true>), dim3(a.nblocks), dim3(256), 0, ctx->stream, a, d.p);
+    else if (t->cs_h) hipLaunchKernelGGL(k_nn_counters<1>, dim3(a.nblocks), dim3(256), 0, ctx->stream, a, d.p);
     else hipLaunchKernelGGL(k_nn_counters<0>, dim3(a.nblocks), dim3(256), 0, ctx->stream, a, d.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h, d.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));

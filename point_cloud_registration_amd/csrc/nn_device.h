@@ -222,42 +222,64 @@ __device__ __forceinline__ void nn_scan_range_lb(const PtF *__restrict__ pts, co
     }
     const uint32_t g1 = (e - 1u) >> 6;
 #if PCR_LB_BATCHED
-    // The first version walked the boxes one by one -- box, test, next box: a chain of ~16 dependent round trips for a query in
-    // a 300-point cell, five times the chain of a query in an ordinary cell, and the pass took that much longer.  Here FOUR
-    // boxes are requested together at either level (8 loads in flight), the survivors are remembered in a bit mask (no indexed
-    // register arrays), and a leaf's 8 records are one batch of 8 loads.
+    // Boxes are requested FOUR at a time (8 loads in flight) instead of one by one, and -- what matters -- the NEAREST box of a
+    // batch is opened first: a range is entered with `best` still at the search bound (the gate, 2 m), against which every box
+    // of the cell passes; the first version opened them in storage order and paid ~130 loads per converged query in a
+    // 600-point cell before its bound became useful.  With the nearest group and, inside it, the nearest leaf first, the bound
+    // is at the match distance after one leaf and everything else is re-tested against THAT.  Survivors are kept in bit masks
+    // (no dynamically indexed register arrays); the two phases share one instance of the loop body.
     const uint32_t l_first = s >> 3, l_last = (e - 1u) >> 3;
     const float inf = __int_as_float(0x7f800000);
     for (uint32_t G = s >> 6; G <= g1; G += 4u) {
-        uint32_t gm = 0;
+        float dg[4];
 #pragma unroll
         for (uint32_t u = 0; u < 4u; ++u) {
             const uint32_t gi = min(G + u, g1);
             const float4 lo = gbox[2u * gi], hi = gbox[2u * gi + 1u];
-            const float d = G + u <= g1 ? box_d2(lo, hi, qx, qy, qz) : inf;
-            gm |= (d <= best ? 1u : 0u) << u;
+            dg[u] = G + u <= g1 ? box_d2(lo, hi, qx, qy, qz) : inf;
         }
         if (STATS) st->cand += 8;
-        while (gm) {
-            const uint32_t Gi = G + (uint32_t)__builtin_ctz(gm);
-            gm &= gm - 1u;
-            const uint32_t l0 = max(l_first, Gi << 3), l1 = min(l_last, (Gi << 3) + 7u);
-            for (uint32_t L = l0; L <= l1; L += 4u) {
-                uint32_t lm = 0;
+        uint32_t gmin = 0; float dgm = dg[0];
 #pragma unroll
-                for (uint32_t v = 0; v < 4u; ++v) {
-                    const uint32_t li = min(L + v, l1);
+        for (uint32_t u = 1; u < 4u; ++u) { const bool c = dg[u] < dgm; gmin = c ? u : gmin; dgm = c ? dg[u] : dgm; }
+#pragma unroll 1
+        for (int gphase = 0; gphase < 2; ++gphase) {
+            uint32_t gm = 0;
+            if (gphase == 0) gm = dgm <= best ? 1u << gmin : 0u;
+            else {
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) gm |= (u != gmin && dg[u] <= best ? 1u : 0u) << u;
+            }
+            while (gm) {
+                const uint32_t Gi = G + (uint32_t)__builtin_ctz(gm);
+                gm &= gm - 1u;
+                const uint32_t l0 = max(l_first, Gi << 3), l1 = min(l_last, (Gi << 3) + 7u);
+                float dl[8];
+#pragma unroll
+                for (uint32_t v = 0; v < 8u; ++v) {
+                    const uint32_t li = min(l0 + v, l1);
                     const float4 lo = lbox[2u * li], hi = lbox[2u * li + 1u];
-                    const float d = L + v <= l1 ? box_d2(lo, hi, qx, qy, qz) : inf;
-                    lm |= (d <= best ? 1u : 0u) << v;
+                    dl[v] = l0 + v <= l1 ? box_d2(lo, hi, qx, qy, qz) : inf;
                 }
-                if (STATS) st->cand += 8;
-                while (lm) {
-                    const uint32_t Li = L + (uint32_t)__builtin_ctz(lm);
-                    lm &= lm - 1u;
-                    const uint32_t a = max(s, Li << 3), b = min(e, (Li << 3) + 8u);
-                    if (STATS) st->cand += 8;
-                    nn_scan_range<float, PtF, 0, 8>(pts, a, b, qx, qy, qz, best, bj, borig, nullptr);
+                if (STATS) st->cand += 16;
+                uint32_t lmin = 0; float dlm = dl[0];
+#pragma unroll
+                for (uint32_t v = 1; v < 8u; ++v) { const bool c = dl[v] < dlm; lmin = c ? v : lmin; dlm = c ? dl[v] : dlm; }
+#pragma unroll 1
+                for (int lphase = 0; lphase < 2; ++lphase) {
+                    uint32_t lm = 0;
+                    if (lphase == 0) lm = dlm <= best ? 1u << lmin : 0u;
+                    else {
+#pragma unroll
+                        for (uint32_t v = 0; v < 8u; ++v) lm |= (v != lmin && dl[v] <= best ? 1u : 0u) << v;
+                    }
+                    while (lm) {
+                        const uint32_t Li = l0 + (uint32_t)__builtin_ctz(lm);
+                        lm &= lm - 1u;
+                        const uint32_t a = max(s, Li << 3), b = min(e, (Li << 3) + 8u);
+                        if (STATS) st->cand += 8;
+                        nn_scan_range<float, PtF, 0, 8>(pts, a, b, qx, qy, qz, best, bj, borig, nullptr);
+                    }
                 }
             }
         }
@@ -339,9 +361,9 @@ __device__ __forceinline__ int nn_ring0(const Geom<Real> &g, const PT *__restric
         // landed one cell off the surface is served like one inside an occupied cell.
         const uint32_t s_ = w0 & g.cs_mask, e_ = w1 & g.cs_mask;
         if (e_ > s_) {
-            if (STATS) { st->rings++; st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
+            if (STATS) { st->rings++; st->rows_loaded++; st->cand += LB ? 0u : ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
             uint32_t ej = PCR_NONE;
-            if constexpr (LB) nn_scan_range_lb<B>((const PtF *)g.pts_h, g.lbox_h, g.gbox_h, s_, e_, qx, qy, qz, best, ej, borig);
+            if constexpr (LB) nn_scan_range_lb<B, STATS>((const PtF *)g.pts_h, g.lbox_h, g.gbox_h, s_, e_, qx, qy, qz, best, ej, borig, st);
             else nn_scan_range<Real, PT, TRACK, B>((const PT *)g.pts_h, s_, e_, qx, qy, qz, best, ej, borig, tk);
             if (ej != PCR_NONE) bj = g.j_h[ej];
             c.reach0 = g.halo;
@@ -351,8 +373,8 @@ __device__ __forceinline__ int nn_ring0(const Geom<Real> &g, const PT *__restric
         }
     } else if (gap == 0) {
         const uint32_t s_ = w0 & g.cs_mask, e_ = w1 & g.cs_mask;
-        if (STATS) { st->rings++; st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-        if constexpr (LB) nn_scan_range_lb<B>(pts, g.lbox, g.gbox, s_, e_, qx, qy, qz, best, bj, borig);
+        if (STATS) { st->rings++; st->rows_loaded++; st->cand += LB ? 0u : ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
+        if constexpr (LB) nn_scan_range_lb<B, STATS>(pts, g.lbox, g.gbox, s_, e_, qx, qy, qz, best, bj, borig, st);
         else nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
         return 1;
     }
@@ -426,19 +448,19 @@ __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restri
                     }
                     if (xl <= xh) {
                         const uint32_t s_ = cs[row + (uint32_t)xl] & g.cs_mask, e_ = cs[row + (uint32_t)xh + 1u] & g.cs_mask;
-                        if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-                        if constexpr (LB) nn_scan_range_lb<B>(pts, g.lbox, g.gbox, s_, e_, qx, qy, qz, best, bj, borig); else nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
+                        if (STATS) { st->rows_loaded++; st->cand += LB ? 0u : ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
+                        if constexpr (LB) nn_scan_range_lb<B, STATS>(pts, g.lbox, g.gbox, s_, e_, qx, qy, qz, best, bj, borig, st); else nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
                     }
                 } else {                                    // interior row of the ring: its two end cells
                     if (xa_in && dyz2 + dxa <= PB) {
                         const uint32_t s_ = cs[row + (uint32_t)xa] & g.cs_mask, e_ = cs[row + (uint32_t)xa + 1u] & g.cs_mask;
-                        if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-                        if constexpr (LB) nn_scan_range_lb<B>(pts, g.lbox, g.gbox, s_, e_, qx, qy, qz, best, bj, borig); else nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
+                        if (STATS) { st->rows_loaded++; st->cand += LB ? 0u : ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
+                        if constexpr (LB) nn_scan_range_lb<B, STATS>(pts, g.lbox, g.gbox, s_, e_, qx, qy, qz, best, bj, borig, st); else nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
                     }
                     if (xb_in && dyz2 + dxb <= PB) {
                         const uint32_t s_ = cs[row + (uint32_t)xb] & g.cs_mask, e_ = cs[row + (uint32_t)xb + 1u] & g.cs_mask;
-                        if (STATS) { st->rows_loaded++; st->cand += ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-                        if constexpr (LB) nn_scan_range_lb<B>(pts, g.lbox, g.gbox, s_, e_, qx, qy, qz, best, bj, borig); else nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
+                        if (STATS) { st->rows_loaded++; st->cand += LB ? 0u : ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
+                        if constexpr (LB) nn_scan_range_lb<B, STATS>(pts, g.lbox, g.gbox, s_, e_, qx, qy, qz, best, bj, borig, st); else nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
                     }
                 }
             }

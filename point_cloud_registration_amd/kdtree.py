@@ -24,6 +24,11 @@ class KDTree:
         # float32 data (the PCD case) is searched in float32; a float64 array is searched in float64, as every backend of
         # the reference does with the dtype it is given (kdtree.py:18-21): float32 filter search
         # over the index + float64 check / box search, the float64 search's neighbour in every case
+        # Limits of the float64 emulation: QUERY points are taken as float32 (what every registration class passes,
+        # registration.py:83) and up-cast; k > 1 searches the float32 copy of the data; and coordinates float32 cannot resolve
+        # (UTM-scale clouds: a point moves by more than a quarter cell when rounded) keep the float32 search with a
+        # RuntimeWarning instead of failing -- the reference's float64 tree would differ there only between near-equidistant
+        # neighbours.
         self._target = _capi.Target.points(ctx, data.astype(np.float32, copy=False))
         if data.dtype == np.float64 and self.n > 0:
             self._target.set_points_f64(data)

@@ -1288,3 +1288,36 @@ def test_centroid_filter_everything_pending(capi, orc, ctx):
         for a, b in zip(*outs):
             assert a[28] > 0.5 * len(src)
             assert np.array_equal(a, b)
+
+
+def test_q6_fallback_on_utm_scale_float64_target(capi, ctx):
+    """a float64 cloud at UTM-scale coordinates (float32 ulp 0.03-0.5 m) cannot carry the float64 search through the
+    float32 index; ``KDTree`` / ``PlaneICP.set_target`` must keep working on the float32 copy (as before quirk Q6 was
+    reproduced) with a warning -- not raise a misleading "not those of the target's float32 points"."""
+    import warnings
+    import point_cloud_registration_amd as pcr
+    rng = np.random.default_rng(5)
+    tgt = rng.uniform(-20, 20, (20000, 3)) + np.array([4.0e6, 5.0e6, 100.0])
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        tree = pcr.KDTree(tgt)
+        d, i = tree.query(tgt[:100].astype(np.float32))
+        reg = pcr.PlaneICP(max_dist=5.0, k=8)
+        reg.set_target(tgt)
+        H, g, e2 = reg.calc_H_g_e2(np.eye(4), tgt[:5000].astype(np.float32))
+    assert any(issubclass(x.category, RuntimeWarning) for x in w)
+    assert d.shape == (100,) and np.all(np.isfinite(d)) and np.all(np.isfinite(H))
+
+
+def test_internal_flag_bits_are_masked(capi, orc, ctx):
+    """bits 27-29 of the flags word are internal (gate switch of quirk Q6, developer timing switches); a caller
+    passing them must get the ordinary, gated result."""
+    from point_cloud_registration_amd.synthetic import street, perturbed_scan
+    target = street(30000, seed=4)
+    scan, _ = perturbed_scan(target, 8000, seed=5)
+    t = capi.Target.points(ctx, target)
+    sc = capi.Scan(ctx, scan)
+    T = np.eye(4); T[:3, 3] = [0.4, 0.3, 0.2]
+    a = capi.linearize(t, sc, capi.ICP, T, 0.3, capi.FLAG_ICP_RR_QUIRK)
+    b = capi.linearize(t, sc, capi.ICP, T, 0.3, capi.FLAG_ICP_RR_QUIRK | (1 << 27) | (1 << 28) | (1 << 29))
+    assert np.array_equal(a, b) and a[28] < scan.shape[0]          # some points ARE gated out at 0.3 m

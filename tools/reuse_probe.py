@@ -29,7 +29,10 @@ target = B.make_cloud(n_target, seed=0, config=a.config)
 scan, T_true = B.make_scan(a.config, target, n_scan, a.scan, seed=2)
 if kind_name in ("icp", "plane"):
     tgt = _capi.Target.points(ctx, target)
-    if kind_name == "plane":
+    if kind_name == "plane" and "lidar" in a.config:
+        from point_cloud_registration_amd.synthetic import lidar_normals
+        tgt.set_normals(lidar_normals(target))
+    elif kind_name == "plane":
         tgt.estimate_normals(15, compat=n_target <= 2_000_000, want=False)
 else:
     tgt = _capi.Target.voxels(ctx, target, voxel_size, 10)
