@@ -736,12 +736,21 @@ static pcr_status make_row_occ(pcr_context *ctx, const uint32_t *cs, Geom<Real> 
     return PCR_OK;
 }
 
-// leaf / group boxes (Geom::lbox, gbox): min / max corner of every 8 and of every 64 consecutive records of a point array
-// (its sentinel records excluded).  One thread per leaf; the 8 leaves of a group sit in 8 neighbouring lanes.
-__global__ void __launch_bounds__(256) k_leaf_boxes(const PtF *__restrict__ pts, int64_t n, float4 *__restrict__ lbox, float4 *__restrict__ gbox) {
+// leaf / group boxes (Geom::lbox, gbox): the box of every 8 and of every 64 consecutive records of a point array (its sentinel
+// records excluded), ONE 16-byte record each: the min corner exactly, the extents as 10-bit counts of qe = cell / 256 rounded up
+// plus one, 1023 = unbounded (nn_device.h: box_d2).  One thread per leaf; the 8 leaves of a group sit in 8 neighbouring lanes.
+__device__ __forceinline__ uint32_t box_extent_q(float lo, float hi, float inv_qe, float extra) {
+    // extra = 1 + the grid's rounding slack in counts: the decoded max corner fma(count, qe, lo) errs by an ulp of the COORDINATE,
+    // which at |p| ~ 1e5 m exceeds qe; the slack (16 ulp of the largest coordinate) always covers it
+    const float c = ceilf((hi - lo) * inv_qe) + extra;
+    return c >= 1023.f || !(c == c) ? 1023u : (uint32_t)c;
+}
+__global__ void __launch_bounds__(256) k_leaf_boxes(const PtF *__restrict__ pts, int64_t n, float qe, float extra, float4 *__restrict__ lbox,
+                                                    float4 *__restrict__ gbox) {
     const int64_t L = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t nleaf = (n + 7) >> 3;
     const float inf = __builtin_inff();
+    const float inv_qe = 1.f / qe;
     float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
     if (L < nleaf) {
         const int64_t j1 = min((L << 3) + 8, n);
@@ -751,8 +760,8 @@ __global__ void __launch_bounds__(256) k_leaf_boxes(const PtF *__restrict__ pts,
             lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
             lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
         }
-        lbox[2 * L] = make_float4(lo[0], lo[1], lo[2], 0.f);
-        lbox[2 * L + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+        const uint32_t w = box_extent_q(lo[0], hi[0], inv_qe, extra) | box_extent_q(lo[1], hi[1], inv_qe, extra) << 10 | box_extent_q(lo[2], hi[2], inv_qe, extra) << 20;
+        lbox[L] = make_float4(lo[0], lo[1], lo[2], __uint_as_float(w));
     }
 #pragma unroll
     for (int off = 1; off < 8; off <<= 1) {
@@ -763,20 +772,21 @@ __global__ void __launch_bounds__(256) k_leaf_boxes(const PtF *__restrict__ pts,
         }
     }
     if ((threadIdx.x & 7) == 0 && L < nleaf) {
-        gbox[2 * (L >> 3)] = make_float4(lo[0], lo[1], lo[2], 0.f);
-        gbox[2 * (L >> 3) + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+        const uint32_t w = box_extent_q(lo[0], hi[0], inv_qe, extra) | box_extent_q(lo[1], hi[1], inv_qe, extra) << 10 | box_extent_q(lo[2], hi[2], inv_qe, extra) << 20;
+        gbox[L >> 3] = make_float4(lo[0], lo[1], lo[2], __uint_as_float(w));
     }
 }
 
-// boxes over `n` records (+ a few leaves of padding so that a scan that over-reads a batch into the sentinels finds a box)
-static pcr_status make_leaf_boxes(pcr_context *ctx, const PtF *pts, int64_t n, float4 **lbox_out, float4 **gbox_out) {
+// boxes over `n` records (+ a few records of padding: the batched scan clamps its indices, nothing reads beyond the last box)
+static pcr_status make_leaf_boxes(pcr_context *ctx, const PtF *pts, int64_t n, float cell, float slack, float4 **lbox_out, float4 **gbox_out) {
     *lbox_out = nullptr; *gbox_out = nullptr;
     if (n <= 0) return PCR_OK;
     const int64_t nleaf = (n + 7) >> 3, ngroup = (nleaf + 7) >> 3;
     DevBuf<float4> lb, gb;
-    HIP_TRY(lb.alloc_exact((size_t)(2 * nleaf + 8)));
-    HIP_TRY(gb.alloc_exact((size_t)(2 * ngroup + 8)));
-    hipLaunchKernelGGL(k_leaf_boxes, dim3((unsigned)((nleaf + 255) / 256)), dim3(256), 0, ctx->stream, pts, n, lb.p, gb.p);
+    HIP_TRY(lb.alloc_exact((size_t)(nleaf + 8)));
+    HIP_TRY(gb.alloc_exact((size_t)(ngroup + 8)));
+    hipLaunchKernelGGL(k_leaf_boxes, dim3((unsigned)((nleaf + 255) / 256)), dim3(256), 0, ctx->stream, pts, n, cell * 0.00390625f,
+                       1.f + ceilf(slack / (cell * 0.00390625f)), lb.p, gb.p);
     HIP_TRY(hipGetLastError());
     *lbox_out = lb.release(); *gbox_out = gb.release();
     return PCR_OK;
@@ -901,10 +911,10 @@ pcr_status pcr_build_point_grid(pcr_context *ctx, const float *d_xyz, int64_t n,
                                            halo, &t->cs_h, &t->pts_h, &t->j_h, &t->n_h, use_env ? &heavy : nullptr)));
     t->heavy = heavy;
     if (heavy) {                  // leaf / group boxes over the cell-sorted points and over the extended lists
-        PCR_TRY(make_leaf_boxes(ctx, t->pts, n, &t->lbox, &t->gbox));
+        PCR_TRY(make_leaf_boxes(ctx, t->pts, n, t->gf.h, t->gf.slack, &t->lbox, &t->gbox));
         t->gf.lbox = t->lbox; t->gf.gbox = t->gbox;
         if (t->pts_h) {
-            PCR_TRY(make_leaf_boxes(ctx, t->pts_h, t->n_h, &t->lbox_h, &t->gbox_h));
+            PCR_TRY(make_leaf_boxes(ctx, t->pts_h, t->n_h, t->gf.h, t->gf.slack, &t->lbox_h, &t->gbox_h));
             t->gf.lbox_h = t->lbox_h; t->gf.gbox_h = t->gbox_h;
         }
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -943,7 +953,7 @@ pcr_status pcr_build_deep_lists(pcr_context *ctx, pcr_target *t) {
     t->n_h2 = n_h;
     t->cs_h2 = cs_h.release(); t->pts_h2 = pts_h.release(); t->j_h2 = j_h.release();
     if (t->heavy) {
-        PCR_TRY(make_leaf_boxes(ctx, t->pts_h2, n_h, &t->lbox_h2, &t->gbox_h2));
+        PCR_TRY(make_leaf_boxes(ctx, t->pts_h2, n_h, t->gf.h, t->gf.slack, &t->lbox_h2, &t->gbox_h2));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     return PCR_OK;

@@ -199,10 +199,20 @@ struct NNStats { uint32_t rings, rows_loaded, rows_pruned, cand; };
 // |q - p| >= the clamped delta per axis, float subtraction and dist2_f32 are monotone under round-to-nearest, so this is a lower
 // bound on the COMPUTED distance of every record inside -- exactly, no slack.  A box is skipped when it exceeds `best`
 // strictly: a record AT the best distance (which could win on the smaller index) is always looked at.
-__device__ __forceinline__ float box_d2(const float4 &lo, const float4 &hi, float qx, float qy, float qz) {
-    const float dx = fmaxf(fmaxf(lo.x - qx, qx - hi.x), 0.f);
-    const float dy = fmaxf(fmaxf(lo.y - qy, qy - hi.y), 0.f);
-    const float dz = fmaxf(fmaxf(lo.z - qz, qz - hi.z), 0.f);
+// A box is ONE 16-byte record (round 6, second form: two float4 per box made a converged query in a 600-point cell pay 90 loads,
+// 2/3 of them boxes): {lo.x, lo.y, lo.z, extents}, the min corner exactly and the three extents as 10-bit counts of
+// qe = cell edge / 256, rounded UP plus one (1023 = unbounded on that axis: a block that straddles rows of cells).  The decoded
+// max corner fma(count, qe, lo) errs by an ulp of the coordinate against a margin of one qe: it never lies below a record.
+__device__ __forceinline__ float box_d2(const float4 &b, float qe, float qx, float qy, float qz) {
+    const uint32_t w = __float_as_uint(b.w);
+    const uint32_t ex = w & 1023u, ey = (w >> 10) & 1023u, ez = (w >> 20) & 1023u;
+    const float inf = __int_as_float(0x7f800000);
+    const float hx = ex == 1023u ? inf : __builtin_fmaf((float)ex, qe, b.x);
+    const float hy = ey == 1023u ? inf : __builtin_fmaf((float)ey, qe, b.y);
+    const float hz = ez == 1023u ? inf : __builtin_fmaf((float)ez, qe, b.z);
+    const float dx = fmaxf(fmaxf(b.x - qx, qx - hx), 0.f);
+    const float dy = fmaxf(fmaxf(b.y - qy, qy - hy), 0.f);
+    const float dz = fmaxf(fmaxf(b.z - qz, qz - hz), 0.f);
     return dist2_f32(dx, dy, dz);
 }
 // Records [s, e) of `pts`: short ranges plainly; longer ones group by group (64 records) and leaf by leaf (8 records), each
@@ -212,7 +222,7 @@ __device__ __forceinline__ float box_d2(const float4 &lo, const float4 &hi, floa
 #define PCR_LB_BATCHED 1
 #endif
 template <int B = PCR_NN_BATCH, bool STATS = false>
-__device__ __forceinline__ void nn_scan_range_lb(const PtF *__restrict__ pts, const float4 *__restrict__ lbox, const float4 *__restrict__ gbox,
+__device__ __forceinline__ void nn_scan_range_lb(const PtF *__restrict__ pts, const float4 *__restrict__ lbox, const float4 *__restrict__ gbox, float qe,
                                                  uint32_t s, uint32_t e, float qx, float qy, float qz,
                                                  float &best, uint32_t &bj, uint32_t &borig, NNStats *st = nullptr) {
     if (e - s <= PCR_LB_MIN) {
@@ -235,10 +245,10 @@ __device__ __forceinline__ void nn_scan_range_lb(const PtF *__restrict__ pts, co
 #pragma unroll
         for (uint32_t u = 0; u < 4u; ++u) {
             const uint32_t gi = min(G + u, g1);
-            const float4 lo = gbox[2u * gi], hi = gbox[2u * gi + 1u];
-            dg[u] = G + u <= g1 ? box_d2(lo, hi, qx, qy, qz) : inf;
+            const float4 bx = gbox[gi];
+            dg[u] = G + u <= g1 ? box_d2(bx, qe, qx, qy, qz) : inf;
         }
-        if (STATS) st->cand += 8;
+        if (STATS) st->cand += 4;
         uint32_t gmin = 0; float dgm = dg[0];
 #pragma unroll
         for (uint32_t u = 1; u < 4u; ++u) { const bool c = dg[u] < dgm; gmin = c ? u : gmin; dgm = c ? dg[u] : dgm; }
@@ -258,10 +268,10 @@ __device__ __forceinline__ void nn_scan_range_lb(const PtF *__restrict__ pts, co
 #pragma unroll
                 for (uint32_t v = 0; v < 8u; ++v) {
                     const uint32_t li = min(l0 + v, l1);
-                    const float4 lo = lbox[2u * li], hi = lbox[2u * li + 1u];
-                    dl[v] = l0 + v <= l1 ? box_d2(lo, hi, qx, qy, qz) : inf;
+                    const float4 bx = lbox[li];
+                    dl[v] = l0 + v <= l1 ? box_d2(bx, qe, qx, qy, qz) : inf;
                 }
-                if (STATS) st->cand += 16;
+                if (STATS) st->cand += 8;
                 uint32_t lmin = 0; float dlm = dl[0];
 #pragma unroll
                 for (uint32_t v = 1; v < 8u; ++v) { const bool c = dl[v] < dlm; lmin = c ? v : lmin; dlm = c ? dl[v] : dlm; }
@@ -286,14 +296,14 @@ __device__ __forceinline__ void nn_scan_range_lb(const PtF *__restrict__ pts, co
     }
 #else
     for (uint32_t G = s >> 6; G <= g1; ++G) {
-        const float4 glo = gbox[2u * G], ghi = gbox[2u * G + 1u];
-        if (STATS) st->cand += 2;
-        if (box_d2(glo, ghi, qx, qy, qz) > best) continue;
+        const float4 gb = gbox[G];
+        if (STATS) st->cand += 1;
+        if (box_d2(gb, qe, qx, qy, qz) > best) continue;
         const uint32_t l0 = max(s >> 3, G << 3), l1 = min((e - 1u) >> 3, (G << 3) + 7u);
         for (uint32_t L = l0; L <= l1; ++L) {
-            const float4 llo = lbox[2u * L], lhi = lbox[2u * L + 1u];
-            if (STATS) st->cand += 2;
-            if (box_d2(llo, lhi, qx, qy, qz) > best) continue;
+            const float4 lb = lbox[L];
+            if (STATS) st->cand += 1;
+            if (box_d2(lb, qe, qx, qy, qz) > best) continue;
             const uint32_t a = max(s, L << 3), b = min(e, (L << 3) + 8u);
             if (STATS) st->cand += ((b - a + 3) / 4) * 4;
             nn_scan_range<float, PtF, 0, 4>(pts, a, b, qx, qy, qz, best, bj, borig, nullptr);
@@ -363,7 +373,7 @@ __device__ __forceinline__ int nn_ring0(const Geom<Real> &g, const PT *__restric
         if (e_ > s_) {
             if (STATS) { st->rings++; st->rows_loaded++; st->cand += LB ? 0u : ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
             uint32_t ej = PCR_NONE;
-            if constexpr (LB) nn_scan_range_lb<B, STATS>((const PtF *)g.pts_h, g.lbox_h, g.gbox_h, s_, e_, qx, qy, qz, best, ej, borig, st);
+            if constexpr (LB) nn_scan_range_lb<B, STATS>((const PtF *)g.pts_h, g.lbox_h, g.gbox_h, g.h * 0.00390625f, s_, e_, qx, qy, qz, best, ej, borig, st);
             else nn_scan_range<Real, PT, TRACK, B>((const PT *)g.pts_h, s_, e_, qx, qy, qz, best, ej, borig, tk);
             if (ej != PCR_NONE) bj = g.j_h[ej];
             c.reach0 = g.halo;
@@ -374,7 +384,7 @@ __device__ __forceinline__ int nn_ring0(const Geom<Real> &g, const PT *__restric
     } else if (gap == 0) {
         const uint32_t s_ = w0 & g.cs_mask, e_ = w1 & g.cs_mask;
         if (STATS) { st->rings++; st->rows_loaded++; st->cand += LB ? 0u : ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-        if constexpr (LB) nn_scan_range_lb<B, STATS>(pts, g.lbox, g.gbox, s_, e_, qx, qy, qz, best, bj, borig, st);
+        if constexpr (LB) nn_scan_range_lb<B, STATS>(pts, g.lbox, g.gbox, g.h * 0.00390625f, s_, e_, qx, qy, qz, best, bj, borig, st);
         else nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
         return 1;
     }
@@ -449,18 +459,18 @@ __device__ __forceinline__ void nn_rings(const Geom<Real> &g, const PT *__restri
                     if (xl <= xh) {
                         const uint32_t s_ = cs[row + (uint32_t)xl] & g.cs_mask, e_ = cs[row + (uint32_t)xh + 1u] & g.cs_mask;
                         if (STATS) { st->rows_loaded++; st->cand += LB ? 0u : ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-                        if constexpr (LB) nn_scan_range_lb<B, STATS>(pts, g.lbox, g.gbox, s_, e_, qx, qy, qz, best, bj, borig, st); else nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
+                        if constexpr (LB) nn_scan_range_lb<B, STATS>(pts, g.lbox, g.gbox, g.h * 0.00390625f, s_, e_, qx, qy, qz, best, bj, borig, st); else nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
                     }
                 } else {                                    // interior row of the ring: its two end cells
                     if (xa_in && dyz2 + dxa <= PB) {
                         const uint32_t s_ = cs[row + (uint32_t)xa] & g.cs_mask, e_ = cs[row + (uint32_t)xa + 1u] & g.cs_mask;
                         if (STATS) { st->rows_loaded++; st->cand += LB ? 0u : ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-                        if constexpr (LB) nn_scan_range_lb<B, STATS>(pts, g.lbox, g.gbox, s_, e_, qx, qy, qz, best, bj, borig, st); else nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
+                        if constexpr (LB) nn_scan_range_lb<B, STATS>(pts, g.lbox, g.gbox, g.h * 0.00390625f, s_, e_, qx, qy, qz, best, bj, borig, st); else nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
                     }
                     if (xb_in && dyz2 + dxb <= PB) {
                         const uint32_t s_ = cs[row + (uint32_t)xb] & g.cs_mask, e_ = cs[row + (uint32_t)xb + 1u] & g.cs_mask;
                         if (STATS) { st->rows_loaded++; st->cand += LB ? 0u : ((e_ - s_ + PCR_NN_BATCH - 1) / PCR_NN_BATCH) * PCR_NN_BATCH; }
-                        if constexpr (LB) nn_scan_range_lb<B, STATS>(pts, g.lbox, g.gbox, s_, e_, qx, qy, qz, best, bj, borig, st); else nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
+                        if constexpr (LB) nn_scan_range_lb<B, STATS>(pts, g.lbox, g.gbox, g.h * 0.00390625f, s_, e_, qx, qy, qz, best, bj, borig, st); else nn_scan_range<Real, PT, TRACK, B>(pts, s_, e_, qx, qy, qz, best, bj, borig, tk);
                     }
                 }
             }

@@ -70,8 +70,8 @@ struct Geom {
     // of its cells: clouds are surfaces, and a surface fills a small part of the cells it crosses.
     const uint2 *rbox;
     int nxr;
-    // leaf / group boxes (float32 point targets with HEAVY cells, nullptr = none; round 6): lbox[2 L], lbox[2 L + 1] = min / max
-    // corner of records [8 L, 8 L + 8) of the cell-sorted array, gbox the same for records [64 G, 64 G + 64) -- fixed blocks of
+    // leaf / group boxes (float32 point targets with HEAVY cells, nullptr = none; round 6): lbox[L] = the box of records
+    // [8 L, 8 L + 8) of the cell-sorted array (one 16-byte record: nn_device.h box_d2), gbox[G] the same for records [64 G, 64 G + 64) -- fixed blocks of
     // the ARRAY, so a block may straddle cells (its box is then looser, never wrong).  The points of a cell are sorted along a
     // Morton curve inside the cell, so a block is a compact patch.  A range of more than PCR_LB_MIN records is scanned box by
     // box (nn_scan_range_lb): a cell of a LiDAR sweep's inner rings holds hundreds of points where the average cell holds five.

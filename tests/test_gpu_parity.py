@@ -1321,3 +1321,50 @@ def test_internal_flag_bits_are_masked(capi, orc, ctx):
     a = capi.linearize(t, sc, capi.ICP, T, 0.3, capi.FLAG_ICP_RR_QUIRK)
     b = capi.linearize(t, sc, capi.ICP, T, 0.3, capi.FLAG_ICP_RR_QUIRK | (1 << 27) | (1 << 28) | (1 << 29))
     assert np.array_equal(a, b) and a[28] < scan.shape[0]          # some points ARE gated out at 0.3 m
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_heavy_index_fuzz(capi, orc, ctx, seed, monkeypatch):
+    """The heavy-cell index (round 6: Morton-sorted cells, 16-byte leaf / group boxes, nearest-first box scans) against brute force:
+    clouds made of a sparse background, dense blobs and dense LINES (hundreds to thousands of points per cell), at the origin and
+    at |p| ~ 1e4 m (where the boxes' quantisation margin has to grow with the coordinates' ulp), queries inside, near and far;
+    index and distance bit for bit, for the query seam, the search + reduce kernels and the fused small-scan kernel."""
+    rng = np.random.default_rng(100 + seed)
+    off = np.array([0.0, 0.0, 0.0]) if seed % 2 == 0 else np.array([9000.0, -7000.0, 300.0])
+    n_bg = 20000
+    parts = [rng.uniform(-20, 20, (n_bg, 3)) * [1, 1, 0.1]]
+    for _ in range(4):                                             # blobs
+        c = rng.uniform(-15, 15, 3) * [1, 1, 0.1]
+        parts.append(c + rng.normal(0, rng.uniform(0.02, 0.3), (int(rng.integers(500, 6000)), 3)))
+    for _ in range(4):                                             # lines
+        a, b = rng.uniform(-18, 18, 3) * [1, 1, 0.1], rng.uniform(-18, 18, 3) * [1, 1, 0.1]
+        t = rng.uniform(0, 1, int(rng.integers(2000, 20000)))[:, None]
+        parts.append(a + t * (b - a) + rng.normal(0, 0.01, (t.shape[0], 3)))
+    if seed == 5:                                                  # exact duplicates: ties go to the smaller original index
+        parts.append(np.repeat(parts[1][:50], 40, axis=0))
+    target = (np.concatenate(parts) + off).astype(np.float32)
+    target = target[rng.permutation(target.shape[0])]
+    monkeypatch.setenv("PCR_HEAVY", "1")
+    if seed == 3:
+        monkeypatch.setenv("PCR_GRID_CELL", "1.5")                 # very heavy cells
+    t = capi.Target.points(ctx, target)
+    info = t.index_info()
+    assert info["heavy"] and info["pop_max"] > 64, info
+    q = np.concatenate([target[rng.choice(target.shape[0], 3000)] + rng.normal(0, 0.02, (3000, 3)),
+                        target[rng.choice(target.shape[0], 2000)] + rng.normal(0, 0.6, (2000, 3)),
+                        rng.uniform(-30, 30, (1000, 3)) * [1, 1, 0.3] + off]).astype(np.float32)
+    d, i = t.nn_query(q)
+    do, io = orc.nn_brute(target, q)
+    assert np.array_equal(i, io) and np.array_equal(d, do)
+    db, ib = t.nn_query(q, 0.5)                                    # bounded
+    keep = do < 0.5
+    assert np.array_equal(ib[keep], io[keep]) and np.all(ib[~keep] == -1)
+    ot = orc.TargetPoints(target, cell=1.0)
+    T = np.eye(4); T[:3, 3] = [0.05, -0.03, 0.02]
+    for scan in (q, np.concatenate([q] * 60)):                     # fused small-scan kernel / search + reduce kernels
+        sc = capi.Scan(ctx, scan)
+        H, g, e2, cnt = capi.unpack29(capi.linearize(t, sc, capi.ICP, T, 1.0))
+        Ho, go, e2o, cnto = orc.calc_H_g_e2(orc.ICP, ot, T, scan, 1.0, with_count=True)
+        assert cnt == cnto and rel_H(H, Ho) < 1e-9 and abs(e2 - e2o) <= 1e-9 * abs(e2o)
+        sc.close()
+    t.close()
