@@ -1,0 +1,27 @@
+"""The heavy-cell form of the point index (round 6: cell floor, Morton-sorted cells, 16-byte leaf / group boxes, box-aware range
+scans -- csrc/nn_device.h: nn_scan_range_lb) is chosen by the build only for clouds whose heaviest cell is far above the average
+(LiDAR sweeps).  Here EVERY point target of the search-exactness tests is forced through it (PCR_HEAVY=1) in a fresh process: the
+32 fuzz seeds against the oracle, the cell-boundary stress test, the query seam, the align loops, the reference fixtures --
+the same assertions (indices and distances bit for bit, sums <= 1e-9) on the other search path."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def test_search_exactness_suite_on_the_heavy_index():
+    env = dict(os.environ, PCR_HEAVY="1")
+    expr = ("fuzz_against_oracle or nn_stress or nn_query or fuzz_knn or knn_constructed or align_matches_reference or "
+            "linearize_masked or robustness_edge or deeper_list_set or g8_hip or b01_sampled or b01_shard")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(REPO, "tests", "test_gpu_parity.py"),
+                        os.path.join(REPO, "tests", "test_gpu_fullsize.py"), "-m", "gpu", "-x", "-q", "-k", expr, "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, timeout=2400, env=env, cwd=REPO)
+    tail = r.stdout[-1500:]
+    assert r.returncode == 0, tail + r.stderr[-500:]
+    assert " passed" in tail, tail
+    print(tail.splitlines()[-1])

@@ -1297,7 +1297,7 @@ def test_q6_fallback_on_utm_scale_float64_target(capi, ctx):
     import warnings
     import point_cloud_registration_amd as pcr
     rng = np.random.default_rng(5)
-    tgt = rng.uniform(-20, 20, (20000, 3)) + np.array([4.0e6, 5.0e6, 100.0])
+    tgt = rng.uniform(-20, 20, (20000, 3)) + np.array([4.0e7, 5.0e7, 100.0])     # float32 ulp 4 m: no usable band
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         tree = pcr.KDTree(tgt)

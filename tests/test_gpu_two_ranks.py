@@ -56,13 +56,17 @@ def _worker(rank, world, port, q, transport=None):
             # spin inside k_p2p_allreduce (bounded) and must come out with the same sums
             import time
             acc = []
+            t_pass = time.perf_counter()
             for i in range(70):
                 Tq = np.array(g2["T"], dtype=np.float64); Tq[0, 3] += 1e-3 * i
                 if i == 10 and rank == world - 1:
                     time.sleep(0.05)
                 Hq, gq, e2q = reg.calc_H_g_e2(Tq, shard)
                 acc.append(np.concatenate([Hq.ravel(), gq, [e2q]]))
+            # (per-pass wall time of this rank, the 50 ms nap included once: time-sliced ranks on one GPU, so a latency bound on
+            # the exchange, not a scaling number -- profiles/r06_p2p_ranks.txt)
             out["wrap"] = (np.array(acc), None, 0, 0)
+            out["pass_ms"] = ((time.perf_counter() - t_pass - (0.05 if rank == world - 1 else 0.0)) / 70 * 1e3, None, 0, 0)
     failed = ctx.comm_p2p_failed() if (comm.in_library and comm.transport == "p2p") else False
     q.put((rank, comm.in_library, out, comm.transport, failed))
     dist.barrier()
@@ -105,6 +109,8 @@ def test_two_ranks_one_gpu_sharded_plane_icp(g2, transport, world):
         assert not any(r[4] for r in res)
         for r in res[1:]:
             assert np.array_equal(res[0][2]["wrap"][0], r[2]["wrap"][0]), "ranks disagree after the wrap / the late rank"
+        print(f"p2p world {world}: calc_H_g_e2 of a {2000 // world}-point shard incl. the exchange, ms per pass and rank:",
+              [round(r[2]["pass_ms"][0], 4) for r in res])
     for name in ("plane", "icp", "vplane", "ndt"):
         (Ta, Ha, ita, ca) = out_a[name]
         for r in res[1:]:
