@@ -197,6 +197,8 @@ extern "C" pcr_status pcr_context_create(int device, pcr_context **out) {
     if (fa && *fa) ctx->filter_after = atoi(fa);
     const char *vo = getenv("PCR_VOX_OCC");
     if (vo && *vo) ctx->vox_occ = atoi(vo) != 0;
+    const char *psp = getenv("PCR_PHASE_SPLIT");
+    if (psp && *psp) ctx->phase_split = atoi(psp) != 0;
     const char *tl = getenv("PCR_TILE_LOCAL");
     if (tl && *tl) ctx->tile_local = atoi(tl) != 0;
     const char *sd = getenv("PCR_STALL_DEBUG");

@@ -471,6 +471,126 @@ __global__ void __launch_bounds__(256, FIX ? 4 : 1) k_reduce_finalize(const LinA
     // would cap this streaming kernel at 3 blocks per CU; k_gn_update runs it as a 1-wave launch)
 }
 
+// Round 6 (the tail of an iteration at B-01 size).  Search AND reduce of a mid-size scan over a point
+// target in ONE launch -- PHASE-SPLIT, not interleaved: the fused small-scan kernel (k_linearize_finalize) keeps the 32
+// float64 accumulators alive across every search and pays for them with half the occupancy of k_nn_scan (measured slower from
+// ~300 k points on); here a block first SEARCHES all the tiles of its block-local hand-out exactly as k_nn_scan<.., LOCAL = 1>
+// does (matches to nn_j, 73-80 VGPRs' worth of live state), meets at one barrier, and only then walks the same tile list
+// again -- dealt to its four waves STATICALLY, so the order of every sum is fixed whatever the timing of the search -- to
+// gather and accumulate, folds and takes its ticket.  The accumulators exist only in the second phase: the kernel's register
+// count is the maximum of the two phases, not their sum.  What it saves is the reduce kernel as a LAUNCH: at 1.06 M points
+// k_reduce_finalize is a 22-us chain (launch, cold gathers, fold, two ticket levels) of which the stream itself is a third;
+// inside the search kernel that work runs in the shadow of the other blocks' searches and only the last block's fold is left.
+// The sums differ from the search + reduce pair's in the last bits (another association of the same terms), so a context
+// runs ONE of the two forms for a given scan size, and the certified-reuse modes (whose tests compare sums across modes bit
+// for bit) keep the pair.
+#ifndef PCR_PS_WAVES
+#define PCR_PS_WAVES 5
+#endif
+template <int KIND, int HALO>
+__global__ void __launch_bounds__(256, PCR_PS_WAVES) k_scan_reduce(const LinArgs a, const FinArgs f) {
+    static_assert(KIND == PCR_ICP || KIND == PCR_PLANE, "point targets only");
+    PoseK P;
+    if (!load_pose<false>(a, P)) return;
+    {
+        PoseQ Q;                                    // (tracking searches only: unused)
+        const Geom<float> gsel = HALO ? select_lists(a) : a.gf;
+        nn_tile_loop<1, 64>(a, [&](int64_t first, int64_t end) {
+            const int64_t i = first + (threadIdx.x & 63);
+            if (i < end) nn_point<0, HALO, 0, 0>(a, gsel, P, Q, i);
+        });
+    }
+    // the block's matches are in nn_j: workgroup-scope release / acquire around the barrier (one CU, one L1)
+    __syncthreads();
+    // (the float64 rotation only now: 18 scalar registers the search has no room for)
+    if (a.pose == nullptr) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) P.R[i] = a.hp.R[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) P.R[i] = uniform_f64(a.pose->R[i]);
+    }
+    // The accumulators are SPLIT over the two halves of the wave: lanes l and l + 32 take the SAME scan point (32 points of a
+    // tile per step), the lower lane carries components 0..15 of the 32-vector, the upper lane components 16..31 -- 16 float64
+    // accumulators per lane instead of 32 (the whole-vector form needs > 96 VGPRs: 251 spilled at 5 waves / SIMD).  That is
+    // exactly the state wave_fold32 is in after its first halving step, so the fold simply starts at the second one.
+    double acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+    {
+        // the tile list of nn_tile_loop<1, 64> (virtual tile xb + k nxb of this XCD, chunk-interleaved), wave w takes
+        // k = w, w + 4, ...; both halves' gathers in flight, accumulated in index order
+        const int xcd = (int)(blockIdx.x & 7);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const bool upper = lane >= 32;
+        const int64_t xb = blockIdx.x >> 3, nxb = gridDim.x >> 3;
+        const int64_t chunk = (int64_t)PCR_TILE_CHUNK * 64;
+        const int64_t nchunks = (a.n + chunk - 1) / chunk;
+        const int64_t vspan = ((nchunks + 7) / 8) * chunk;
+        for (int64_t k = wave;; k += 4) {
+            const int64_t vfirst = (xb + k * nxb) * 64;
+            if (vfirst >= vspan) break;
+            const int64_t first = nn_tile_real<64>(a, xcd, 0, vfirst);
+            if (first >= a.n) break;                // (wave-uniform: real positions grow with k)
+#pragma unroll 1
+            for (int u = 0; u < 2; ++u) {
+                const int64_t ipu = first + (lane & 31) + 32 * u;
+                const uint32_t ju = ipu < a.n ? a.nn_j[ipu] : PCR_NONE;
+                if (ju == PCR_NONE) continue;
+                float4 qu, nru = make_float4(0, 0, 0, 0);
+                if (KIND == PCR_PLANE) { const float4 *r = reinterpret_cast<const float4 *>(a.pn + ju); qu = r[0]; nru = r[1]; }
+                else qu = a.pts[ju];
+                const float xf = a.sx[ipu], yf = a.sy[ipu], zf = a.sz[ipu];
+                float tx, ty, tz;
+                xform(P, xf, yf, zf, tx, ty, tz);
+                const float dxf = tx - qu.x, dyf = ty - qu.y, dzf = tz - qu.z;
+                if (!gate_f32(a, dxf, dyf, dzf)) continue;
+                const double x = xf, y = yf, z = zf, d0 = dxf, d1 = dyf, d2 = dzf;
+                if (KIND == PCR_PLANE) {
+                    // acc_plane / acc_rank1, component by component (plane_icp.py:49-67)
+                    const double n0 = nru.x, n1 = nru.y, n2 = nru.z;
+                    const double r = (n0 * d0 + n1 * d1) + n2 * d2;
+                    const double ra = P.R[0] * n0 + P.R[3] * n1 + P.R[6] * n2;
+                    const double rb = P.R[1] * n0 + P.R[4] * n1 + P.R[7] * n2;
+                    const double rc = P.R[2] * n0 + P.R[5] * n1 + P.R[8] * n2;
+                    const double J3 = -z * rb + y * rc, J4 = z * ra - x * rc, J5 = -y * ra + x * rb;
+                    if (!upper) {
+                        acc[0] = fma(n0, n0, acc[0]); acc[1] = fma(n0, n1, acc[1]); acc[2] = fma(n0, n2, acc[2]);
+                        acc[3] = fma(n0, J3, acc[3]); acc[4] = fma(n0, J4, acc[4]); acc[5] = fma(n0, J5, acc[5]);
+                        acc[6] = fma(n1, n1, acc[6]); acc[7] = fma(n1, n2, acc[7]); acc[8] = fma(n1, J3, acc[8]);
+                        acc[9] = fma(n1, J4, acc[9]); acc[10] = fma(n1, J5, acc[10]);
+                        acc[11] = fma(n2, n2, acc[11]); acc[12] = fma(n2, J3, acc[12]); acc[13] = fma(n2, J4, acc[13]);
+                        acc[14] = fma(n2, J5, acc[14]);
+                        acc[15] = fma(J3, J3, acc[15]);
+                    } else {
+                        acc[0] = fma(J3, J4, acc[0]); acc[1] = fma(J3, J5, acc[1]);
+                        acc[2] = fma(J4, J4, acc[2]); acc[3] = fma(J4, J5, acc[3]);
+                        acc[4] = fma(J5, J5, acc[4]);
+                        acc[5] = fma(n0, r, acc[5]); acc[6] = fma(n1, r, acc[6]); acc[7] = fma(n2, r, acc[7]);
+                        acc[8] = fma(J3, r, acc[8]); acc[9] = fma(J4, r, acc[9]); acc[10] = fma(J5, r, acc[10]);
+                        acc[11] = fma(r, r, acc[11]);
+                        acc[12] += 1.0;
+                    }
+                } else {
+                    // acc_icp's 17 components: 0..15 on the lower lane, e2 (16) on the upper one
+                    if (!upper) {
+                        double full[32];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) full[i] = acc[i];
+                        full[16] = 0.0;
+                        acc_icp(full, P, a.flags, x, y, z, d0, d1, d2);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[i] = full[i];
+                    } else {
+                        acc[0] += d0 * d0 + d1 * d1 + d2 * d2;
+                    }
+                }
+            }
+        }
+    }
+    (void)ticket_fold_emit<true>(acc, a, f);
+}
+
 // GN (device-resident loop on one GPU): the block that emits also takes the Gauss-Newton step.  This kernel runs one
 // tile per wave at 129-191 VGPRs anyway, so -- unlike in the streaming reduce kernel -- the step's registers cost no
 // occupancy, and the iteration saves the k_gn_update launch (~8 us of a 46 us iteration on a 100 k-point scan).  Every
@@ -567,6 +687,8 @@ pcr_status pcr_ensure_scratch(pcr_context *ctx, int64_t n_points) {
             ctx->nn_blocks_rb = (e == hipSuccess && nb > 0) ? nb : 4;
             const hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_nn_scan<0, 1, 0, 0, 2>, 256, 0);
             ctx->nn_blocks_lb = (e2 == hipSuccess && nb > 0) ? nb : 4;
+            const hipError_t e3 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_scan_reduce<PCR_PLANE, 1>, 256, 0);
+            ctx->nn_blocks_ps = (e3 == hipSuccess && nb > 0) ? nb : 4;
         }
         for (int v = 0; v < 4; ++v) {
             int nb = 0;
@@ -916,6 +1038,39 @@ static pcr_status pass_enqueue(Pass *ps) {
             }
             if (ctx->tile_local >= 0) local = ctx->tile_local;
             ps->a.sched_local = local;
+            // Round 6: plain full search of a point target with the block-local hand-out -> search + reduce in ONE phase-split
+            // launch (k_scan_reduce).  Not for the certified-reuse modes (their tests compare sums across modes bit for bit and
+            // the two forms associate the same terms differently), heavy targets (leaf boxes: 111 VGPRs) or developer searches.
+            if (ctx->phase_split && !vox && !ps->q6 && mode == PCR_NN_FULL && ctx->nn_mode == 0 && ps->fused_fin && ctx->reuse == 0 &&
+                local == 1 && a.gf.lbox == nullptr && a.gf.rbox == nullptr && a.n > 0) {
+                int64_t nbs = (int64_t)ctx->num_cu * ctx->nn_blocks_ps;
+                if (nbs > need) nbs = need;
+                nbs = (nbs + 7) & ~(int64_t)7;
+                if (nbs < 8) nbs = 8;
+                if (nbs <= ctx->max_blocks && tiles <= nbs * 4 * 8) {
+                    // host-driven pass: the list set by how far the scan moved since the previous pass (unknown: the deeper one)
+                    if (a.pose == nullptr && a.halo2_f > 0.f && !(ps->motion >= 0.0 && ps->motion < ps->f.deep_len)) {
+                        ps->a.gf.halo = a.halo2_f; ps->a.gf.cs_h = a.cs_h2; ps->a.gf.pts_h = a.pts_h2; ps->a.gf.j_h = a.j_h2;
+                        ps->a.gf.lbox_h = a.lbox_h2; ps->a.gf.gbox_h = a.gbox_h2;
+                    }
+                    FinArgs f2 = ps->f;
+                    f2.nblocks = (int)nbs;                      // tickets and group rows follow THIS grid
+                    const dim3 sgrid((unsigned)nbs);
+                    if (ev.kernel >= 0) ev.kernel = PCR_K_LINEARIZE;       // (the event opened above: nothing launched under it yet)
+                    const bool halo = ps->t->cs_h != nullptr;
+                    if (ps->kind == PCR_ICP) {
+                        if (halo) hipLaunchKernelGGL((k_scan_reduce<PCR_ICP, 1>), sgrid, block, 0, ctx->stream, a, f2);
+                        else hipLaunchKernelGGL((k_scan_reduce<PCR_ICP, 0>), sgrid, block, 0, ctx->stream, a, f2);
+                    } else {
+                        if (halo) hipLaunchKernelGGL((k_scan_reduce<PCR_PLANE, 1>), sgrid, block, 0, ctx->stream, a, f2);
+                        else hipLaunchKernelGGL((k_scan_reduce<PCR_PLANE, 0>), sgrid, block, 0, ctx->stream, a, f2);
+                    }
+                    pcr_prof_end(ctx, &ev);
+                    ps->s->nn_serial = ps->t->serial;
+                    HIP_TRY(hipGetLastError());
+                    return PCR_OK;
+                }
+            }
 #ifdef PCR_DEV
             // (developer build, nn_mode 4: the MFMA-filtered search on every plain full search of a point target)
             const bool mfma = !vox && !ps->q6 && mode == PCR_NN_FULL && ps->t->n > 0 && ctx->nn_mode == 4;

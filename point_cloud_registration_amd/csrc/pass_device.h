@@ -347,8 +347,11 @@ __device__ __forceinline__ void fold_step(double *acc, int lane) {
 }
 
 // After the call lane l holds the wave-wide sum of component (l >> 1) in acc[0].
+// SPLIT (k_scan_reduce): the lanes come in holding 16 values each -- components 0..15 on lanes 0..31, 16..31 on lanes 32..63 --
+// i.e. the state after the first halving step.
+template <bool SPLIT = false>
 __device__ __forceinline__ void wave_fold32(double *acc, int lane) {
-    fold_step<16, 32>(acc, lane);
+    if (!SPLIT) fold_step<16, 32>(acc, lane);
     fold_step<8, 16>(acc, lane);
     fold_step<4, 8>(acc, lane);
     fold_step<2, 4>(acc, lane);
@@ -358,11 +361,11 @@ __device__ __forceinline__ void wave_fold32(double *acc, int lane) {
 
 // COHERENT: the store is written through to memory at agent scope, so that a block on ANOTHER XCD
 // (each XCD has a private, mutually non-coherent L2) can read it inside the same kernel.
-template <bool COHERENT = false>
+template <bool COHERENT = false, bool SPLIT = false>
 __device__ __forceinline__ void block_store_partials(double *acc, double *__restrict__ partials) {
     __shared__ double wsum[4][32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    wave_fold32(acc, lane);
+    wave_fold32<SPLIT>(acc, lane);
     if ((lane & 1) == 0) wsum[wave][lane >> 1] = acc[0];
     __syncthreads();
     if (threadIdx.x < 32) {
@@ -899,8 +902,9 @@ __device__ __forceinline__ void finalize_emit(const FinArgs &f, const double *to
 // last of the 8 second-level tickets folds those rows and emits.  8 x (nblocks/8) + 8 serialised atomics
 // instead of nblocks.
 // (returns true in the ONE block that folded the last contribution and emitted the result)
+template <bool SPLIT = false>
 __device__ __forceinline__ bool ticket_fold_emit(double *acc, const LinArgs &a, const FinArgs &f) {
-    block_store_partials<true>(acc, a.partials);
+    block_store_partials<true, SPLIT>(acc, a.partials);
 
     __shared__ int role;
     __shared__ double part[8][33];
