@@ -1001,7 +1001,8 @@ pcr_status pcr_build_centroid_filter(pcr_context *ctx, pcr_target *t) {
     // centroid, i.e. a good part of a (two-voxel) cell, at EVERY pose, and the lists of a few hundred thousand centroids stay in
     // the caches whatever their depth.  Search us per 6-pose trajectory, margin 0.1 / 0.25 / 0.4 / 0.5 / 0.6 / 0.8 / 1.0 cell:
     // vplane_10m 3699 / 3643 / 3382 / 3473 / 3397 / 3683 / 3466, ndt_10m 2559 / 2434 / 2252 / 2244 / 2207 / 2590 / 2649.
-    PCR_TRY(pcr_build_point_grid(ctx, xyz.p, t->n, (float)g.h, f, false, 0.4));
+    static const double halo_env = getenv("PCR_FILTER_HALO") ? atof(getenv("PCR_FILTER_HALO")) : 0.0;     // (developer: sweep)
+    PCR_TRY(pcr_build_point_grid(ctx, xyz.p, t->n, (float)g.h, f, false, halo_env > 0.0 ? halo_env : 0.4));
     t->filter_band = band;
     return PCR_OK;
 }

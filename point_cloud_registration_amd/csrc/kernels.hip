@@ -485,7 +485,7 @@ __global__ void __launch_bounds__(256, FIX ? 4 : 1) k_reduce_finalize(const LinA
 // runs ONE of the two forms for a given scan size, and the certified-reuse modes (whose tests compare sums across modes bit
 // for bit) keep the pair.
 #ifndef PCR_PS_WAVES
-#define PCR_PS_WAVES 5
+#define PCR_PS_WAVES 4      // (5: the reduce phase spills 104 bytes per lane and the pass is slower still, profiles/r06_phase_split_null.txt)
 #endif
 template <int KIND, int HALO>
 __global__ void __launch_bounds__(256, PCR_PS_WAVES) k_scan_reduce(const LinArgs a, const FinArgs f) {
@@ -1044,6 +1044,10 @@ static pcr_status pass_enqueue(Pass *ps) {
             if (ctx->phase_split && !vox && !ps->q6 && mode == PCR_NN_FULL && ctx->nn_mode == 0 && ps->fused_fin && ctx->reuse == 0 &&
                 local == 1 && a.gf.lbox == nullptr && a.gf.rbox == nullptr && a.n > 0) {
                 int64_t nbs = (int64_t)ctx->num_cu * ctx->nn_blocks_ps;
+                {   // (developer: more than one resident generation of blocks, PCR_PS_GRID_MULT)
+                    static const double mult = getenv("PCR_PS_GRID_MULT") ? atof(getenv("PCR_PS_GRID_MULT")) : 1.0;
+                    if (mult > 0.0) nbs = (int64_t)((double)nbs * mult);
+                }
                 if (nbs > need) nbs = need;
                 nbs = (nbs + 7) & ~(int64_t)7;
                 if (nbs < 8) nbs = 8;

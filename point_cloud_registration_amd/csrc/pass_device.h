@@ -597,6 +597,21 @@ __device__ __forceinline__ void nn_tile_loop(const LinArgs &a, Body &&body) {
 #endif
 }
 
+// The match of a plain pass goes to HBM for the reduce kernel, which reads it from another XCD more often than not.  Round 6
+// tried a NON-TEMPORAL store here (-DPCR_NNJ_NT=1: global_store_dword ... nt), so that the 4 bytes per scan point would not sit
+// dirty in the writing XCD's L2 until the end-of-kernel release (40 MB on a 10 M-point scan): no gain on any config, the reduce
+// kernel of ndt_10m 5 % slower (its index stream then comes from HBM); profiles/r06_nt_ab.txt.  Plain stores stay.
+#ifndef PCR_NNJ_NT
+#define PCR_NNJ_NT 0
+#endif
+__device__ __forceinline__ void nnj_store(uint32_t *p, uint32_t v) {
+#if PCR_NNJ_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // One query: scan point i, on its own lane (gathers): the general search.  HALO: the target has the extended
 // per-cell lists and ring 0 reads those (nn_ring0).
 // TRACK = 0: the match is gated here (PCR_NONE = no correspondence) -- nothing else is left behind.
@@ -647,7 +662,7 @@ __device__ __forceinline__ void nn_point(const LinArgs &a, const Geom<float> &gf
             a.lb2[i] = __builtin_sqrtf(lb2q) * 0.99999f;
         } else {
             const bool ok = bo != PCR_NONE && __builtin_sqrtf(best) < a.md_f;
-            a.nn_j[i] = ok ? bj : PCR_NONE;
+            nnj_store(a.nn_j + i, ok ? bj : PCR_NONE);
         }
     } else {
         double best = a.bound2_d, lb2q;
@@ -667,7 +682,7 @@ __device__ __forceinline__ void nn_point(const LinArgs &a, const Geom<float> &gf
             a.lb2[i] = (float)(__builtin_sqrt(lb2q) * 0.99999);
         } else {
             const bool ok = bo != PCR_NONE && __builtin_sqrt(best) < a.md_d;
-            a.nn_j[i] = ok ? bj : PCR_NONE;
+            nnj_store(a.nn_j + i, ok ? bj : PCR_NONE);
         }
     }
 }
@@ -742,7 +757,7 @@ __device__ __forceinline__ void nn_point_filter(const LinArgs &a, const PoseK &P
         out = PCR_PENDING_BIT | w;                   // (cert is only ever false with a nominee: w != PCR_NONE)
         atomicMax(a.pending, a.stamp);
     }
-    a.nn_j[i] = out;
+    nnj_store(a.nn_j + i, out);
 }
 
 // The float64 answer for a point nn_point_filter could not certify.  The filter left its NOMINEE behind (nn_j =

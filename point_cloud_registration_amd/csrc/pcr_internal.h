@@ -245,7 +245,7 @@ struct pcr_context {
     int nn_blocks_rb = 4;               // ... of k_nn_scan<0, ., ., FULL, RB = 1> (row-block boxes)
     int nn_blocks_lb = 4;               // ... of k_nn_scan<0, ., ., FULL, RB = 2> (leaf / group boxes)
     int nn_blocks_ps = 4;               // ... of k_scan_reduce (phase-split search + reduce, round 6)
-    int phase_split = 1;                // PCR_PHASE_SPLIT=0: mid-size scans over point targets run k_nn_scan + k_reduce_finalize instead
+    int phase_split = 0;                // PCR_PHASE_SPLIT=1 (opt-in; measured slower, profiles/r06_phase_split_null.txt): mid-size scans over point targets run k_scan_reduce instead of k_nn_scan + k_reduce_finalize
     uint32_t filter_stamp = 0;          // stamp of the last k_nn_filter pass (k_nn_fix)
     // profiling
     bool prof_on = false;

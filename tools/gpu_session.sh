@@ -15,7 +15,7 @@ for step in "$@"; do
   IFS=: read -r kind a b c <<< "$step"
   echo "=== [$tag] $step (PCR_LIB=${PCR_LIB:-shipped})"
   case $kind in
-    tests) (cd $root && timeout 1500 python -m pytest tests -m gpu -x -q -rs > $out/${tag}_pytest.log 2>&1; echo "rc=$?" >> $out/${tag}_pytest.log; tail -4 $out/${tag}_pytest.log) ;;
+    tests) (cd $root && timeout 1500 python -m pytest tests -m gpu -x -q -rs --durations=40 > $out/${tag}_pytest.log 2>&1; echo "rc=$?" >> $out/${tag}_pytest.log; tail -4 $out/${tag}_pytest.log) ;;
     quick) (cd $root && timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "fuzz_against_oracle or nn_stress or nn_query or certified_reuse or fuzz_knn or centroid_filter" > $out/${tag}_quick.log 2>&1; echo "rc=$?" >> $out/${tag}_quick.log; tail -3 $out/${tag}_quick.log) ;;
     bench) cfg=""; [ "$a" != default ] && cfg="--config $a"
            (cd $root && timeout 1200 python bench.py $cfg ${BENCH_ARGS:-} 2> $out/${tag}_bench_$a.err | tail -1 | tee $out/${tag}_bench_$a.json) ;;

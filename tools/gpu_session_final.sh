@@ -4,7 +4,7 @@
 # rocprofv3 kernel-trace / PMC summaries, per-pose probes, set_target side, seam probes, soak, rare-event trace, 2-rank bench.
 cd "$(dirname "$0")/.."; TAG=${1:-r06}
 o=gpurun_out; mkdir -p $o; export TMPDIR=/tmp
-timeout 3000 python -m pytest tests -m gpu -x -q -rs > $o/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $o/${TAG}_pytest_gpu.log; tail -4 $o/${TAG}_pytest_gpu.log
+timeout 3000 python -m pytest tests -m gpu -x -q -rs --durations=40 > $o/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $o/${TAG}_pytest_gpu.log; tail -4 $o/${TAG}_pytest_gpu.log
 for c in plane_b01 icp_b01 icp_b01_harness plane_b01_100k vplane_b01_harness ndt_b01_harness vplane_10m ndt_10m plane_b01_resampled plane_b01_crop plane_lidar icp_lidar_harness plane_100m plane_100m_resampled; do
     timeout 1500 python bench.py --config $c > $o/${TAG}_bench_$c.json 2> $o/${TAG}_bench_$c.err
     python - "$o/${TAG}_bench_$c.json" <<'PY'
