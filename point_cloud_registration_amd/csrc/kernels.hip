@@ -179,8 +179,10 @@ __global__ void __launch_bounds__(256, VOXEL == 2 ? PCR_VOX_WAVES : (RB ? 4 : 5)
         __shared__ uint32_t lst_n;
         nn_chunk_loop(a, [&](int64_t first, int64_t end) { nn_chunk_list<VOXEL, HALO>(a, P, Q, lst, &lst_n, first, end); });
     } else {
-        // (LOCAL == 2 = the device-resident loop: the list set of this iteration was decided by k_gn_update)
-        const Geom<float> gsel = (!VOXEL && HALO && LOCAL == 2) ? select_lists(a) : a.gf;
+        // (the device-resident loop: the list set of this iteration was decided by k_gn_update.  Round 6: also under LOCAL == 1 --
+        // since round 5's chunk interleave made the block-local hand-out the policy of every mid-size scan, the loop's searches
+        // ran as LOCAL == 1 launches and read the FIRST list set at every iteration; select_lists is a no-op for host-driven passes)
+        const Geom<float> gsel = (!VOXEL && HALO && LOCAL != 0 && MODE == PCR_NN_FULL) ? select_lists(a) : a.gf;
         auto body = [&](int64_t first, int64_t end) {
             const int64_t i = first + (threadIdx.x & 63);
             if (i < end) nn_point<VOXEL, HALO, MODE == PCR_NN_TRACK, RB>(a, gsel, P, Q, i);
