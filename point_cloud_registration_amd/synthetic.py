@@ -94,6 +94,34 @@ def street_tiled(n_total, seed=0, per_tile=1_000_000):
     return out
 
 
+def street_tiled_normals(pts, per_tile=1_000_000):
+    """Analytic unit normals of a ``street_tiled`` cloud (float32, axis-aligned: exactly representable), from the point order
+    and the coordinates alone -- tile by tile what ``street_normals`` does for one street, with each tile's centre recovered
+    from the mid-range of its own ground points (``street_tiled`` subtracts the global mean afterwards).  The reproducible
+    ``PlaneICP.set_target(target, tree, norm)`` input (plane_icp.py:25-27) of the 1e8-point reference fixture g13."""
+    n_total = pts.shape[0]
+    n_tiles = max(1, int(round(n_total / per_tile)))
+    base = n_total // n_tiles
+    out = np.zeros((n_total, 3), dtype=np.float32)
+    pos = 0
+    for t in range(n_tiles):
+        cnt = base + (1 if t < n_total - base * n_tiles else 0)
+        tile = pts[pos:pos + cnt]
+        n_ground = cnt // 2
+        n_wall = (cnt * 4) // 10
+        g = tile[:n_ground]
+        cy = 0.5 * (float(g[:, 1].min()) + float(g[:, 1].max()))
+        o = out[pos:pos + cnt]
+        o[:n_ground, 2] = 1.0
+        w = tile[n_ground:n_ground + n_wall]
+        ywall = np.abs(np.abs(w[:, 1].astype(np.float64) - cy) - 30.0) < 0.2
+        o[n_ground:n_ground + n_wall, 1] = ywall
+        o[n_ground:n_ground + n_wall, 0] = ~ywall
+        o[n_ground + n_wall:, 2] = 1.0
+        pos += cnt
+    return out
+
+
 def lidar_sweep(n, seed=0, sensor=(-20.0, 5.0, 1.8), rings=64, elev_deg=(-24.8, 15.0),
                 range_limits=(0.5, 150.0), noise=0.02):
     """One revolution of a spinning ``rings``-beam LiDAR standing in the ``street`` geometry (ground z = 0 over

@@ -25,13 +25,19 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 REFERENCE = "/root/reference"
 
 
+SHIM_FAST_BUILD = False
+
+
 def install_pykdtree_shim():
     from scipy.spatial import cKDTree
 
     class KDTree:                                   # pykdtree.kdtree.KDTree stand-in
         def __init__(self, data, leafsize=16):
             self._dtype = np.asarray(data).dtype
-            self._tree = cKDTree(np.asarray(data, dtype=np.float64), leafsize=leafsize)
+            # (SHIM_FAST_BUILD, g13 only: sliding-midpoint splits and loose nodes build a 1e8-point tree several times faster;
+            # the answers of an exact search do not depend on how the tree was built)
+            fast = {"balanced_tree": False, "compact_nodes": False} if SHIM_FAST_BUILD else {}
+            self._tree = cKDTree(np.asarray(data, dtype=np.float64), leafsize=leafsize, **fast)
 
         def query(self, pts, k=1, **kw):
             d, i = self._tree.query(np.asarray(pts, dtype=np.float64), k=k, workers=-1)   # threads: same answers
@@ -449,6 +455,49 @@ def g12():
     d1, i1 = grid.kdtree.query(q)
     out["k1_dist"], out["k1_idx"] = np.asarray(d1), np.asarray(i1)
     np.savez_compressed(os.path.join(HERE, "g12_voxel_filter.npz"), **out)
+
+
+def g13():
+    """BASELINE configs[4] AT CONFIG SIZE, run by the reference itself: target = street_tiled(100_000_000,
+    seed=0), scan = one rank's 12.5 M-point shard (perturbed_scan(target, 12_500_000, seed=5): the scan of
+    tests/test_gpu_fullsize.py::test_100m_plane and of bench.py's plane_100m), PlaneICP with SUPPLIED analytic normals
+    (plane_icp.py:25-27; synthetic.street_tiled_normals -- the reference's own estimator loses every digit of its float32
+    E[pp^T] - mu mu^T at |p| ~ 600 m, estimate_normals.py:56-72, so k-NN normals cannot pin anything at this size) and ICP on
+    the same tree, calc_H_g_e2 (plane_icp.py:30-69, icp.py:24-57) at the identity, at 90 % of the way and at T_true.  The
+    normals are handed over as float64 (axis-aligned unit vectors: exact in either type), which makes the reference form
+    PlaneICP's products in float64; ICP's float32 sums over 1.2e7 rows are what they are (quirk Q5).  ~25 minutes, ~12 GB."""
+    import time
+    import zlib
+    from point_cloud_registration_amd.synthetic import street_tiled, street_tiled_normals, perturbed_scan, make_T, T_TRUE_SO3, T_TRUE_T
+    t0 = time.time()
+    target = street_tiled(100_000_000, seed=0)
+    scan, T_true = perturbed_scan(target, 12_500_000, seed=5)
+    normals = street_tiled_normals(target)
+    T_most = make_T(0.9 * np.array(T_TRUE_SO3), 0.9 * np.array(T_TRUE_T))
+    poses = np.array([np.eye(4), T_most, T_true])
+    out = {"n": np.int64(target.shape[0]), "n_scan": np.int64(scan.shape[0]), "max_dist": 2.0, "poses": poses,
+           "crc32_target": np.int64(zlib.crc32(target.tobytes())), "crc32_scan": np.int64(zlib.crc32(scan.tobytes())),
+           "crc32_normals": np.int64(zlib.crc32(normals.tobytes()))}
+    print(f"G13 clouds: {time.time() - t0:.1f} s", flush=True)
+    t0 = time.time()
+    global SHIM_FAST_BUILD
+    SHIM_FAST_BUILD = True
+    tree = ref.KDTree(target)
+    SHIM_FAST_BUILD = False
+    print(f"G13 KDTree(1e8 points): {time.time() - t0:.1f} s", flush=True)
+    pg = ref.PlaneICP(max_dist=2.0, k=15)
+    pg.set_target(target, tree, normals.astype(np.float64))
+    icp = ref.ICP(max_dist=2.0)
+    icp.kdtree, icp.target, icp._is_target_set = tree, target, True       # (icp.py:17-22 with the tree shared: one 1e8-point build)
+    for cname, obj in (("planeg", pg), ("icp", icp)):
+        Hs, gs, e2s = [], [], []
+        for T in poses:
+            t0 = time.time()
+            H, g, e2 = triple(obj.calc_H_g_e2(T, scan))
+            Hs.append(H); gs.append(g); e2s.append(e2)
+            print(f"G13 {cname} calc_H_g_e2: {time.time() - t0:.1f} s, e2 = {e2:.6f}, H00 = {H[0, 0]:.1f}", flush=True)
+        out[f"{cname}_H"], out[f"{cname}_g"], out[f"{cname}_e2"] = np.array(Hs), np.array(gs), np.array(e2s)
+    np.savez_compressed(os.path.join(HERE, "g13_100m_plane.npz"), **out)
 
 
 if __name__ == "__main__":
