@@ -1,10 +1,12 @@
 """Pin the CPU oracle (oracle/) against golden vectors produced by the reference itself
 (tests/golden/make_golden.py).  No GPU needed."""
 
+import os
+
 import numpy as np
 import pytest
 
-from conftest import step_err, rel_H
+from conftest import step_err, rel_H, REPO
 from oracle import oracle as orc
 
 KINDS = {"icp": orc.ICP, "plane": orc.PLANE, "vplane": orc.VPLANE, "ndt": orc.NDT}
@@ -262,6 +264,31 @@ def test_g10_oracle_matches_reference_at_10m(g10, cname, vs):
         assert rel_H(H, g10[f"{cname}_H"][k]) <= 1e-5, (cname, k, rel_H(H, g10[f"{cname}_H"][k]))
         assert np.max(np.abs(g - g10[f"{cname}_g"][k])) <= 1e-4 * np.max(np.abs(g10[f"{cname}_g"][0])), (cname, k)
         assert abs(e2 - g10[f"{cname}_e2"][k]) <= 1e-4 * abs(g10[f"{cname}_e2"][k]), (cname, k)
+
+
+def test_g13_fixture_and_tiled_normals():
+    """g13 = the reference itself on BASELINE configs[4] at config size (1e8-point target, 12.5 M-point shard; make_golden.py: g13).
+    The 1e8-point runs live elsewhere -- the HIP path in tests/test_gpu_fullsize.py::test_100m_plane (GPU), the oracle in
+    tools/g13_oracle_check.py (10 min, 10 GB: profiles/r06_g13_parity.txt; PCR_SLOW=1 runs it from here).  This test pins what
+    both regenerate: the fixture's shape, and the tile-wise analytic normals against the single-street ones."""
+    from conftest import load_golden
+    from point_cloud_registration_amd.synthetic import street, street_normals, street_tiled, street_tiled_normals
+    g = load_golden("g13_100m_plane.npz")
+    assert int(g["n"]) == 100_000_000 and int(g["n_scan"]) == 12_500_000 and g["poses"].shape == (3, 4, 4)
+    for c in ("planeg", "icp"):
+        assert g[f"{c}_H"].shape == (3, 6, 6) and g[f"{c}_g"].shape == (3, 6) and g[f"{c}_e2"].shape == (3,)
+        assert np.all(np.linalg.eigvalsh(g[f"{c}_H"][2]) > 0) and g[f"{c}_e2"][2] < g[f"{c}_e2"][0]
+    assert g["icp_H"][2][0, 0] == 12_500_000                      # every scan point matched at T_true
+    t = street_tiled(2_000_000, seed=0)
+    n = street_tiled_normals(t)
+    assert n.dtype == np.float32 and set(np.unique(n)) == {0.0, 1.0} and np.all(n.sum(1) == 1.0)
+    one = street(1_000_000, seed=0 * 100003 + 0, center=(0.0, 0.0))
+    assert np.mean(np.all(street_normals(one) == n[:1_000_000], axis=1)) > 0.9999      # (corner points within 0.2 m of two walls may differ)
+    if os.environ.get("PCR_SLOW") == "1":
+        import subprocess, sys
+        r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "g13_oracle_check.py")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-800:]
+        print(r.stdout)
 
 
 def test_g9_quirk_q6_float64_target(g9):
