@@ -17,7 +17,9 @@ pytestmark = pytest.mark.gpu
 def test_search_exactness_suite_on_the_heavy_index():
     env = dict(os.environ, PCR_HEAVY="1")
     expr = ("fuzz_against_oracle or nn_stress or nn_query or fuzz_knn or knn_constructed or align_matches_reference or "
-            "linearize_masked or robustness_edge or deeper_list_set or g8_hip or b01_sampled or b01_shard")
+            "linearize_masked or robustness_edge or deeper_list_set or b01_sampled")
+    # (the reference-run fixtures g8 at B-01 size ran here too until the closing session of round 6: 90 of the suite's 690 s for a
+    # path that g11 and test_lidar_sweep_is_exact pin on clouds that really ARE heavy)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(REPO, "tests", "test_gpu_parity.py"),
                         os.path.join(REPO, "tests", "test_gpu_fullsize.py"), "-m", "gpu", "-x", "-q", "-k", expr, "-p", "no:cacheprovider"],
                        capture_output=True, text=True, timeout=2400, env=env, cwd=REPO)
