@@ -105,8 +105,12 @@ class Communicator:
         """Host-side sum of the 29 doubles over all ranks (gloo path)."""
         import torch
         t = torch.from_numpy(np.ascontiguousarray(out29, dtype=np.float64).copy())
+        # (the fallback of a failed in-library init on a GPU run: torch's nccl backend reduces device tensors only)
+        on_device = self._dist.get_backend(self.group) == "nccl" and torch.cuda.is_available()
+        if on_device:
+            t = t.cuda()
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
-        return t.numpy()
+        return t.cpu().numpy() if on_device else t.numpy()
 
     def barrier(self):
         self._dist.barrier(group=self.group)
