@@ -188,9 +188,11 @@ __device__ __forceinline__ uint32_t sub_morton(const Geom<Real> &g, Real x, Real
 // sub_bits > 0: cell_id = (cell << sub_bits) | Morton code of the position inside the cell.
 // occ[slot + 1] (histogram passes): max over the block of the population its points saw their cells reach (round 6: the probe
 // of the automatic cell size also tells whether some cells are far heavier than the average)
-template <typename Real, typename T>
+// K: the sort key's type -- uint32_t, or (round 6, heavy targets) 64 bits wide so that the sub-cell code gets 18 bits instead of
+// the 6-9 a 32-bit key leaves behind a 24-bit cell id
+template <typename Real, typename T, typename K = uint32_t>
 __global__ void __launch_bounds__(256) k_cell_ids(const T *__restrict__ xyz, int64_t n, Geom<Real> g,
-                                                  uint32_t *cell_id, uint32_t *idx, uint32_t *counts, unsigned long long *occ,
+                                                  K *cell_id, uint32_t *idx, uint32_t *counts, unsigned long long *occ,
                                                   int sub_bits) {
     __shared__ unsigned firsts, popmax;
     if (threadIdx.x == 0) { firsts = 0; popmax = 0; }
@@ -202,7 +204,7 @@ __global__ void __launch_bounds__(256) k_cell_ids(const T *__restrict__ xyz, int
         const Real x = (Real)xyz[3 * i], y = (Real)xyz[3 * i + 1], z = (Real)xyz[3 * i + 2];
         const uint32_t c = cell_of<Real>(g, x, y, z);
         if (cell_id) {
-            cell_id[i] = sub_bits > 0 ? (c << sub_bits) | sub_morton<Real>(g, x, y, z, sub_bits / 3) : c;
+            cell_id[i] = sub_bits > 0 ? ((K)c << sub_bits) | (K)sub_morton<Real>(g, x, y, z, sub_bits / 3) : (K)c;
             idx[i] = (uint32_t)i;
         }
         if (counts) { pop = atomicAdd(&counts[c], 1u) + 1u; first = pop == 1u; }
@@ -227,7 +229,8 @@ static unsigned long long occ_popmax(const unsigned long long *h) {
 // these two steps 10 + 20): head[c] = position of the first record of cell c (the array starts as all-ones, head[ncells] = n);
 // a reverse running minimum then gives every cell -- the empty ones included -- the position of the first record at or behind
 // it, which IS the exclusive prefix of the counts.  occ += the occupied cells.
-__global__ void __launch_bounds__(256) k_cell_heads(const uint32_t *__restrict__ cid, int64_t n, int64_t ncells, uint32_t *head,
+template <typename K = uint32_t>
+__global__ void __launch_bounds__(256) k_cell_heads(const K *__restrict__ cid, int64_t n, int64_t ncells, uint32_t *head,
                                                     unsigned long long *occ, int shift) {
     __shared__ unsigned firsts;
     if (threadIdx.x == 0) firsts = 0;
@@ -235,8 +238,8 @@ __global__ void __launch_bounds__(256) k_cell_heads(const uint32_t *__restrict__
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     bool first = false;
     if (j < n) {
-        const uint32_t c = cid[j] >> shift;               // (shift: the sub-cell bits of a heavy target's sort key)
-        first = j == 0 || (cid[j - 1] >> shift) != c;
+        const uint32_t c = (uint32_t)(cid[j] >> shift);   // (shift: the sub-cell bits of a heavy target's sort key)
+        first = j == 0 || (uint32_t)(cid[j - 1] >> shift) != c;
         if (first) head[c] = (uint32_t)j;
         if (j == 0) head[ncells] = (uint32_t)n;
     }
@@ -598,7 +601,7 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
         HIP_TRY(d_counts.alloc((size_t)ncells + 1));
         HIP_TRY(hipMemsetAsync(d_counts.p, 0, sizeof(uint32_t) * ((size_t)ncells + 1), ctx->stream));
         HIP_TRY(hipMemsetAsync(d_nz.p, 0, sizeof(unsigned long long) * OCC_WORDS, ctx->stream));
-        hipLaunchKernelGGL((k_cell_ids<Real, T>), dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, g,
+        hipLaunchKernelGGL((k_cell_ids<Real, T, uint32_t>), dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, g,
                            (uint32_t *)nullptr, (uint32_t *)nullptr, d_counts.p, d_nz.p, 0);
         HIP_TRY(hipMemcpyAsync(h_nz.data(), d_nz.p, sizeof(unsigned long long) * OCC_WORDS, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -648,16 +651,38 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
     // sentinel records behind the last point (see nn_scan_range): +inf coordinates, index ~0
     hipLaunchKernelGGL(k_pad_sentinels<PT>, dim3(1), dim3(64), 0, ctx->stream, d_pts.p + (size_t)n);
     HIP_TRY(hipMemsetAsync(d_nz.p, 0, sizeof(unsigned long long) * OCC_WORDS, ctx->stream));
+    // Heavy targets: minor sort key = Morton code of the position inside the cell.  First version (round 6): as many bits as a
+    // 32-bit key leaves -- 6 behind the 24-bit cell id of the 1.06 M-point LiDAR sweep, i.e. 4 x 4 x 4 sub-cells of 64 mm, each
+    // holding ~60 returns of a ring line in ARBITRARY order: every leaf box of such a sub-cell spans all of it and a converged
+    // query opens them all (67 loads, of which 43 re-tests).  Now a 64-bit key with PCR_HEAVY_SUB_BITS = 18 (64^3 sub-cells of 4 mm
+    // there): 8 consecutive records are 8 neighbours along the line.  <= 9 keeps the 32-bit key.
     int sub_bits = 0;
-    if (heavy) {                  // minor sort key: Morton code of the position inside the cell, as many bits as 32-bit keys leave
-        sub_bits = 32 - bits_for(ncells);
-        sub_bits = sub_bits >= 9 ? 9 : (sub_bits / 3) * 3;
+    bool wide = false;
+    if (heavy) {
+        static const int want = getenv("PCR_HEAVY_SUB_BITS") ? atoi(getenv("PCR_HEAVY_SUB_BITS")) : 18;
+        const int w = (want < 0 ? 0 : (want > 21 ? 21 : want)) / 3 * 3;
+        if (w > 9 && bits_for(ncells) + w <= 64) { sub_bits = w; wide = true; }
+        else {
+            sub_bits = 32 - bits_for(ncells);
+            sub_bits = sub_bits >= 9 ? 9 : (sub_bits / 3) * 3;
+            if (w < sub_bits) sub_bits = w;
+        }
     }
-    if (n > 0) {
-        hipLaunchKernelGGL((k_cell_ids<Real, T>), dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, g, d_cid.p, d_idx.p,
+    if (n > 0 && wide) {
+        DevBuf<unsigned long long> d_key, d_key2;
+        HIP_TRY(d_key.alloc(nn)); HIP_TRY(d_key2.alloc(nn));
+        hipLaunchKernelGGL((k_cell_ids<Real, T, unsigned long long>), dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, g, d_key.p, d_idx.p,
+                           (uint32_t *)nullptr, (unsigned long long *)nullptr, sub_bits);
+        PCR_TRY(sort_pairs<unsigned long long>(ctx, d_key, d_key2, d_idx, d_idx2, n, bits_for(ncells) + sub_bits));
+        hipLaunchKernelGGL(k_cell_heads<unsigned long long>, dim3(nb), dim3(256), 0, ctx->stream, (const unsigned long long *)d_key2.p, n,
+                           (int64_t)ncells, d_counts.p, d_nz.p, sub_bits);
+    } else if (n > 0) {
+        hipLaunchKernelGGL((k_cell_ids<Real, T, uint32_t>), dim3(nb), dim3(256), 0, ctx->stream, d_xyz, n, g, d_cid.p, d_idx.p,
                            (uint32_t *)nullptr, (unsigned long long *)nullptr, sub_bits);
         PCR_TRY(sort_pairs<uint32_t>(ctx, d_cid, d_cid2, d_idx, d_idx2, n, bits_for(ncells) + sub_bits));
-        hipLaunchKernelGGL(k_cell_heads, dim3(nb), dim3(256), 0, ctx->stream, (const uint32_t *)d_cid2.p, n, (int64_t)ncells, d_counts.p, d_nz.p, sub_bits);
+        hipLaunchKernelGGL(k_cell_heads<uint32_t>, dim3(nb), dim3(256), 0, ctx->stream, (const uint32_t *)d_cid2.p, n, (int64_t)ncells, d_counts.p, d_nz.p, sub_bits);
+    }
+    if (n > 0) {
         if (sizeof(Real) == 4)
             hipLaunchKernelGGL(k_gather_f32, dim3(nb), dim3(256), 0, ctx->stream, (const float *)d_xyz,
                                (const uint32_t *)d_idx2.p, n, (PtF *)d_pts.p);
