@@ -200,16 +200,36 @@ __global__ void __launch_bounds__(256) k_cell_ids(const T *__restrict__ xyz, int
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     bool first = false;
     unsigned pop = 0;
+    uint32_t c = 0;
     if (i < n) {
         const Real x = (Real)xyz[3 * i], y = (Real)xyz[3 * i + 1], z = (Real)xyz[3 * i + 2];
-        const uint32_t c = cell_of<Real>(g, x, y, z);
+        c = cell_of<Real>(g, x, y, z);
         if (cell_id) {
             cell_id[i] = sub_bits > 0 ? ((K)c << sub_bits) | (K)sub_morton<Real>(g, x, y, z, sub_bits / 3) : (K)c;
             idx[i] = (uint32_t)i;
         }
-        if (counts) { pop = atomicAdd(&counts[c], 1u) + 1u; first = pop == 1u; }
     }
     if (!counts) return;                 // (ids only: block-uniform)
+    {
+        // histogram pass.  One atomic per DISTINCT cell of the wave (round 6): on a LiDAR sweep hundreds of consecutive returns
+        // fall into one cell, and 64 lanes queueing on one counter made a probing pass 244 us where the street cloud's takes 54.
+        // The leader of each group of equal cells adds the group's size; `pop` = the population the cell reached, `first` = the
+        // group that found it empty.
+        const bool valid = i < n;
+        unsigned long long todo = __ballot(valid);
+        const int lane = threadIdx.x & 63;
+        while (todo) {
+            const int src = __builtin_ctzll(todo);
+            const uint32_t c0 = (uint32_t)__shfl((int)c, src, 64);
+            const unsigned long long same = __ballot(valid && c == c0) & todo;
+            if (lane == src) {
+                const unsigned cnt = (unsigned)__popcll(same);
+                const unsigned old = atomicAdd(&counts[c0], cnt);
+                pop = old + cnt; first = old == 0u;
+            }
+            todo &= ~same;
+        }
+    }
     const unsigned long long m = __ballot(first);
     for (int off = 32; off >= 1; off >>= 1) pop = max(pop, (unsigned)__shfl_xor((int)pop, off, 64));
     if ((threadIdx.x & 63) == 0) { if (m) atomicAdd(&firsts, (unsigned)__popcll(m)); atomicMax(&popmax, pop); }
@@ -583,7 +603,7 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
     // clouds keep cells of the sparse regime and their heavy cells are searched through leaf / group boxes instead (Geom::lbox).
     double h_floor = 0.0;
     unsigned long long pop_max = 0;
-    bool probed = false;
+    bool probed = false, at_floor = false;
     if (auto_h && n > 0) {
         static const double cpp = getenv("PCR_CELLS_PER_POINT") && atof(getenv("PCR_CELLS_PER_POINT")) > 0 ? atof(getenv("PCR_CELLS_PER_POINT")) : 8.0;
         double vol = 1.0;
@@ -611,12 +631,15 @@ static pcr_status build_grid(pcr_context *ctx, const T *d_xyz, int64_t n, double
         const double occ = (double)n / (double)(occupied > 0 ? occupied : 1);
         if (occ > 10.0 && dir <= 0 && !capped) {
             if (h * 0.5 >= h_floor) { h *= 0.5; dir = -1; continue; }
-            if (h > h_floor * 1.05) { h = h_floor; dir = -1; continue; }      // one last probe AT the floor
+            // (round 6, late: no further probe AT the floor -- there the fine adjustment below cannot move h, and whether the cloud
+            // has heavy cells shows in this probe's largest against its average cell just as well; a probing pass over a LiDAR sweep
+            // costs 220 us, four times the street cloud's, since hundreds of waves meet on the counters of its heaviest cells)
+            if (h > h_floor * 1.05) { h = h_floor; at_floor = true; break; }
         }
         if (occ < 2.5 && dir >= 0) { h *= 2.0; dir = 1; continue; }
         break;
     }
-    if (auto_h && n > 0 && occupied > 0 && !capped) {
+    if (auto_h && n > 0 && occupied > 0 && !capped && !at_floor) {
         // fine adjustment: clouds are surfaces, so occupancy of occupied cells grows like h^2; aim at
         // ~5 points per cell (measured optimum on MI355X: fewer candidates per ring-0 cell, still few rows)
         const double occ = (double)n / (double)occupied;
